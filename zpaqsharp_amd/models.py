@@ -1,0 +1,169 @@
+"""Block models used by the tests, fixtures and benchmarks, as ZPAQL config text.
+
+`min`, `mid`, `max` are the three built-in models of the reference
+(`Compressor.startBlock(1..3)`, bytecodes at Compressor.cs:48-74; the ZPAQ
+distribution calls them min.cfg / mid.cfg / max.cfg).  They are kept here as
+*source text*; tests/test_oracle_pins.py checks that assembling them gives the
+reference's hsize (26 / 69 / 196) and header CRCs.
+
+`l1` is the build-defined smallest modelled stream of BASELINE.json configs 1-2
+(SURVEY.md §8d): one direct order-1 CM.  `e8e9` is this repo's own ZPAQL
+post-processor that inverts the reference's forward E8E9 transform
+(LibZPAQ.cs:372-384); BASELINE.json config 5 = `max` model + this PCOMP.
+"""
+from __future__ import annotations
+
+from functools import lru_cache
+
+from .zpaql import Model, assemble
+
+L1_CFG = """
+comp 0 0 0 0 1
+  0 cm 17 255
+hcomp
+  a<<= 9 *d=a halt
+end
+"""
+
+MIN_CFG = """
+comp 1 2 0 0 2
+  0 icm 16
+  1 isse 19 0
+hcomp
+  *b=a a=0 d=0 hash b-- hash *d=a
+  d++ b-- hash b-- hash *d=a
+  halt
+end
+"""
+
+MID_CFG = """
+comp 3 3 0 0 8
+  0 icm 5
+  1 isse 13 0
+  2 isse 17 1
+  3 isse 18 2
+  4 isse 18 3
+  5 isse 19 4
+  6 match 22 24
+  7 mix 16 0 7 24 255
+hcomp
+  c++ *c=a b=c a=0 (save in rotating buffer M)
+  d= 1 hash *d=a   (orders 1..5 for the ISSE chain)
+  b-- d++ hash *d=a
+  b-- d++ hash *d=a
+  b-- d++ hash *d=a
+  b-- d++ hash *d=a
+  b-- d++ hash b-- hash *d=a (order 7 for MATCH)
+  d++ a=*c a<<= 8 *d=a       (order 1 for MIX)
+  halt
+end
+"""
+
+MAX_CFG = """
+comp 5 9 0 0 22
+  0 const 160
+  1 icm 5
+  2 isse 13 1
+  3 isse 16 2
+  4 isse 18 3
+  5 isse 19 4
+  6 isse 19 5
+  7 isse 20 6
+  8 match 22 24
+  9 icm 17
+  10 isse 19 9
+  11 icm 13
+  12 icm 13
+  13 icm 13
+  14 icm 14
+  15 mix 16 0 15 24 255
+  16 mix 8 0 16 10 255
+  17 mix2 0 15 16 24 0
+  18 sse 8 17 32 255
+  19 mix2 8 17 18 16 255
+  20 sse 16 19 32 255
+  21 mix2 0 19 20 16 0
+hcomp
+  c++ *c=a b=c a=0 (save in rotating buffer)
+  d= 2 hash *d=a b-- (orders 1,2,3,4,5,7)
+  d++ hash *d=a b--
+  d++ hash *d=a b--
+  d++ hash *d=a b--
+  d++ hash *d=a b--
+  d++ hash b-- hash *d=a b--
+  d++ hash *d=a b-- (match, order 8)
+  d++ a=*c a&~ 32 (case-insensitive letters -> word orders 0,1 in H[9..10])
+  a> 64 jf 14 a< 91 jf 10
+    d++ hashd d-- *d<>a a+=*d a*= 20 *d=a
+  jmp 9
+    a=*d a== 0 jt 3
+      d++ *d=a d--
+    *d=0
+  d++ d++ b=c b-- a=0 hash *d=a (sparse order-2 contexts)
+  d++ b-- a=0 hash *d=a
+  d++ b-- a=0 hash *d=a
+  d++ a=b a-= 212 b=a a=0 hash *d=a (2-D contexts for tables)
+    b<>a a-= 216 b<>a a=*b a&= 60 hashd
+  d++ a=*c a<<= 9 *d=a (mixer contexts)
+  d++ d++ d++ d++ d++ *d=a
+  halt
+end
+"""
+
+# Inverse E8E9 as a streaming ZPAQL program (own implementation).  M is an
+# 8-byte ring of the most recent input bytes, C counts bytes of the segment.
+# A byte is emitted 4 bytes late, after the 5-byte window starting at it has
+# been tested for (E8|E9) x x x (00|FF) and, on a match, its 24-bit little
+# endian operand has had the window's offset subtracted again.
+E8E9_PCOMP = """
+pcomp e8e9inv ;
+  a> 255 if                      (EOF: flush the pending min(c,4) bytes)
+    a=c a> 4 if a= 4 endif d=a
+    a=c a-=d b=a
+    do a=d a> 0 if
+      a=*b out b++ d--
+    forever endif
+    c=0
+  else
+    *c=a c++
+    a=c a> 4 if
+      b=c b-- a=*b a++ a&= 254 a== 0 if        (5th byte is 00 or FF)
+        a=c a-= 5 b=a
+        a=*b a&= 254 a== 232 if                (1st byte is E8 or E9)
+          b++ b++ b++ a=*b a<<= 8 b-- a|=*b a<<= 8 b-- a|=*b
+          a-=c a+= 5                           (minus the window offset c-5)
+          *b=a a>>= 8 b++ *b=a a>>= 8 b++ *b=a
+        endif
+      endif
+      a=c a-= 5 b=a a=*b out
+    endif
+  endif
+  halt
+end
+"""
+
+
+def _with_pcomp(cfg: str, pcomp: str, pm: int) -> str:
+    """Attach a PCOMP section to a config and set its M size (pm)."""
+    lines = cfg.strip().splitlines()
+    head = lines[0].split()
+    head[4] = str(pm)
+    body = "\n".join(lines[1:])
+    assert body.rstrip().endswith("end")
+    body = body.rstrip()[:-3]
+    return " ".join(head) + "\n" + body + pcomp.strip() + "\n"
+
+
+@lru_cache(maxsize=None)
+def get(name: str) -> Model:
+    """Models by name: l1, min, mid, max, and `<name>+e8e9` for any of them."""
+    base, _, post = name.partition("+")
+    cfg = {"l1": L1_CFG, "min": MIN_CFG, "mid": MID_CFG, "max": MAX_CFG}[base]
+    if post == "":
+        return assemble(cfg)
+    if post == "e8e9":
+        return assemble(_with_pcomp(cfg, E8E9_PCOMP, pm=3))
+    raise KeyError(name)
+
+
+NAMES = ("l1", "min", "mid", "max")
