@@ -1,0 +1,199 @@
+"""Thin Python layer over the C ABI (include/zpaqhip.h): scan, Context, errors.
+
+Everything that decodes goes through libzpaqhip.so and therefore through the
+HIP kernels; nothing here implements or falls back to a CPU decoder.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import Block, Err, Opts, SegResult, Segment, Stats, UINT64_MAX
+
+
+class ZpaqError(RuntimeError):
+    """Raised for any non-zero zpaqhip_status; `.code`, `.block`, `.segment` say where."""
+
+    def __init__(self, code: int, block: int = -1, segment: int = -1, msg: str = ""):
+        self.code, self.block, self.segment = code, block, segment
+        super().__init__(msg or _lib.load().zpaqhip_strerror(code).decode())
+
+
+def _raise(err: Err, rc: int):
+    raise ZpaqError(rc, err.block, err.segment, err.msg.decode(errors="replace"))
+
+
+def _as_u8(data) -> np.ndarray:
+    if isinstance(data, np.ndarray):
+        a = data.view(np.uint8).reshape(-1)
+        return a if a.flags.c_contiguous else np.ascontiguousarray(a)
+    return np.frombuffer(bytes(data) if not isinstance(data, (bytes, bytearray, memoryview)) else data, dtype=np.uint8)
+
+
+def version() -> int:
+    return _lib.load().zpaqhip_version()
+
+
+def device_count() -> int:
+    return _lib.load().zpaqhip_device_count()
+
+
+def strerror(code: int) -> str:
+    return _lib.load().zpaqhip_strerror(code).decode()
+
+
+@dataclass
+class ScanResult:
+    blocks: "C.Array[Block]"
+    segments: "C.Array[Segment]"
+
+    @property
+    def n_blocks(self) -> int:
+        return len(self.blocks)
+
+    @property
+    def n_segments(self) -> int:
+        return len(self.segments)
+
+
+def scan(stream) -> ScanResult:
+    """Host-side framing scan (Decompresser.findBlock/findFilename/readComment/
+    readSegmentEnd, Decompresser.cs:29-108,163-194) → block and segment tables."""
+    L = _lib.load()
+    a = _as_u8(stream)
+    nb, ns, err = C.c_size_t(0), C.c_size_t(0), Err()
+    rc = L.zpaqhip_scan(a.ctypes.data, a.size, None, 0, C.byref(nb), None, 0, C.byref(ns), C.byref(err))
+    if rc:
+        _raise(err, rc)
+    blocks = (Block * max(1, nb.value))()
+    segs = (Segment * max(1, ns.value))()
+    rc = L.zpaqhip_scan(a.ctypes.data, a.size, blocks, nb.value, C.byref(nb), segs, ns.value, C.byref(ns), C.byref(err))
+    if rc:
+        _raise(err, rc)
+    return ScanResult((Block * nb.value).from_buffer(blocks) if nb.value else (Block * 0)(),
+                      (Segment * ns.value).from_buffer(segs) if ns.value else (Segment * 0)())
+
+
+def make_opts(verify_sha1: bool = False, max_concurrent: int = 0, kernel: int = 0, zpaql_budget: int = 0) -> Opts:
+    o = Opts()
+    o.struct_size = C.sizeof(Opts)
+    o.verify_sha1 = int(verify_sha1)
+    o.max_concurrent = max_concurrent
+    o.kernel = kernel
+    o.zpaql_budget = zpaql_budget
+    return o
+
+
+class Context:
+    """One zpaqhip_ctx: bound to one GPU, not thread-safe (LICENSE:44-46 contract)."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.load()
+        h, err = C.c_void_p(), Err()
+        rc = self._L.zpaqhip_ctx_create(device, C.byref(h), C.byref(err))
+        if rc:
+            _raise(err, rc)
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.zpaqhip_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+    def stats(self) -> Stats:
+        s = Stats()
+        self._L.zpaqhip_last_stats(self._h, C.byref(s))
+        return s
+
+    def device_tables(self):
+        """(squash, stretch, dt, dt2k, ns) as read back from device memory."""
+        sq, st = np.zeros(4096, np.uint16), np.zeros(32768, np.int16)
+        dt, dt2k, ns = np.zeros(1024, np.int32), np.zeros(256, np.int32), np.zeros(1024, np.uint8)
+        err = Err()
+        rc = self._L.zpaqhip_read_device_tables(self._h, sq.ctypes.data, st.ctypes.data, dt.ctypes.data,
+                                                dt2k.ctypes.data, ns.ctypes.data, C.byref(err))
+        if rc:
+            _raise(err, rc)
+        return sq, st, dt, dt2k, ns
+
+    def decompress(self, stream, out_cap: Optional[int] = None, **opt) -> np.ndarray:
+        """LibZPAQ.decompress(Reader, Writer) (LibZPAQ.cs:65-79) on host buffers."""
+        a = _as_u8(stream)
+        o = make_opts(**opt)
+        err, n = Err(), C.c_size_t(0)
+        if out_cap is None:
+            sc = scan(a)
+            hints = [b.usize_hint for b in sc.blocks]
+            out_cap = sum(h for h in hints if h != UINT64_MAX) if hints and all(h != UINT64_MAX for h in hints) else 0
+        out = np.empty(max(1, out_cap), np.uint8)
+        rc = self._L.zpaqhip_decompress(self._h, a.ctypes.data, a.size, out.ctypes.data, out_cap, C.byref(n), C.byref(o), C.byref(err))
+        if rc == -20 and n.value > out_cap:             # ZPAQHIP_E_OUTPUT_FULL: now we know the size
+            out_cap = n.value
+            out = np.empty(max(1, out_cap), np.uint8)
+            rc = self._L.zpaqhip_decompress(self._h, a.ctypes.data, a.size, out.ctypes.data, out_cap, C.byref(n), C.byref(o), C.byref(err))
+        if rc:
+            _raise(err, rc)
+        return out[:n.value]
+
+    def decompress_cb(self, read_fn, write_fn, **opt) -> None:
+        """Streaming form: read_fn(n)->bytes ('' at EOF), write_fn(bytes)."""
+        o = make_opts(**opt)
+        err = Err()
+        exc: List[BaseException] = []
+
+        def _r(_u, buf, n):
+            try:
+                b = read_fn(n)
+                C.memmove(buf, b, len(b))
+                return len(b)
+            except BaseException as e:                  # noqa: BLE001 - must not unwind through C
+                exc.append(e)
+                return -1
+
+        def _w(_u, buf, n):
+            try:
+                write_fn(C.string_at(buf, n))
+                return 0
+            except BaseException as e:                  # noqa: BLE001
+                exc.append(e)
+                return -1
+
+        rc = self._L.zpaqhip_decompress_cb(self._h, _lib.READ_FN(_r), _lib.WRITE_FN(_w), None, C.byref(o), C.byref(err))
+        if exc:
+            raise exc[0]
+        if rc:
+            _raise(err, rc)
+
+    def decode_blocks_device(self, d_in: int, in_len: int, sc: ScanResult, d_out: int,
+                             out_off: Sequence[int], out_cap: Sequence[int], ids: Optional[Sequence[int]] = None,
+                             h_in=None, hip_stream: int = 0, raise_on_error: bool = True, **opt):
+        """Explicit block-table form on device buffers (pointers as ints)."""
+        o = make_opts(**opt)
+        err = Err()
+        nsel = len(ids) if ids is not None else sc.n_blocks
+        ids_a = (C.c_uint32 * max(1, nsel))(*ids) if ids is not None else None
+        off_a = (C.c_uint64 * max(1, nsel))(*out_off)
+        cap_a = (C.c_uint64 * max(1, nsel))(*out_cap)
+        res = (SegResult * max(1, sc.n_segments))()
+        h = _as_u8(h_in) if h_in is not None else None
+        rc = self._L.zpaqhip_decode_blocks_device(
+            self._h, d_in, h.ctypes.data if h is not None else None, in_len, sc.blocks, sc.n_blocks, sc.segments,
+            sc.n_segments, ids_a, nsel if ids is not None else 0, d_out, off_a, cap_a, res, C.byref(o),
+            hip_stream or None, C.byref(err))
+        if rc and raise_on_error:
+            _raise(err, rc)
+        return rc, res

@@ -1,0 +1,506 @@
+// zh_api.cpp — C-ABI entry points of libzpaqhip.so (include/zpaqhip.h) and the
+// host driver that turns a block table into kernel launches.
+//
+// There is deliberately no CPU decode path in this file or library: every
+// decoded byte comes out of a HIP kernel, and every entry point that needs a
+// GPU fails with ZPAQHIP_E_NO_DEVICE when none is usable.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "zh_host.h"
+
+extern "C" hipError_t zh_launch_generic(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
+
+namespace zh {
+
+const char *status_message(int code) {
+  switch (code) {
+    case ZPAQHIP_OK: return "ok";
+    case ZPAQHIP_E_CORRUPT: return "archive corrupted";
+    case ZPAQHIP_E_EOF: return "unexpected end of file";
+    case ZPAQHIP_E_EOS: return "decoding end of stream";
+    case ZPAQHIP_E_ZPAQL: return "ZPAQL execution error";
+    case ZPAQHIP_E_HEADER: return "invalid block header";
+    case ZPAQHIP_E_HM_TOO_BIG: return "H too big";
+    case ZPAQHIP_E_COMPONENT: return "invalid component";
+    case ZPAQHIP_E_PP_EOS: return "Unexpected EOS";
+    case ZPAQHIP_E_PP_TYPE: return "unknown post processing type";
+    case ZPAQHIP_E_PP_EMPTY: return "Empty PCOMP";
+    case ZPAQHIP_E_LEVEL: return "unsupported ZPAQ level";
+    case ZPAQHIP_E_SEGMENT: return "missing segment or end of block";
+    case ZPAQHIP_E_FRAMING_EOF: return "unexpected EOF";
+    case ZPAQHIP_E_RESERVED: return "missing reserved byte";
+    case ZPAQHIP_E_SEGEND: return "missing end of segment marker";
+    case ZPAQHIP_E_OUTPUT_FULL: return "output buffer too small";
+    case ZPAQHIP_E_SHA1: return "SHA-1 checksum mismatch";
+    case ZPAQHIP_E_NO_DEVICE: return "no usable HIP device";
+    case ZPAQHIP_E_DEVICE_MEM: return "Out of memory";
+    case ZPAQHIP_E_HIP: return "HIP runtime error";
+    case ZPAQHIP_E_ARG: return "bad argument";
+    case ZPAQHIP_E_BUDGET: return "ZPAQL instruction budget exhausted";
+    case ZPAQHIP_E_CALLBACK: return "read/write callback failed";
+    case ZH_E_SKIPPED: return "segment skipped after an earlier error in its block";
+    default: return "unknown status";
+  }
+}
+
+}  // namespace zh
+
+using namespace zh;
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) cap = n;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct zpaqhip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  DevBuf tables, arena, models, code, bdesc, sdesc, results, queue, in, out;
+  zpaqhip_stats stats{};
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                          \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      char m_[112];                                                           \
+      snprintf(m_, sizeof m_, "HIP: %s (%s)", hipGetErrorString(e_), #expr);  \
+      set_err(err, ZPAQHIP_E_HIP, -1, -1, m_);                                \
+      return ZPAQHIP_E_HIP;                                                   \
+    }                                                                         \
+  } while (0)
+
+zpaqhip_opts resolve_opts(const zpaqhip_opts *o) {
+  zpaqhip_opts r;
+  memset(&r, 0, sizeof r);
+  if (o) memcpy(&r, o, std::min<size_t>(sizeof r, o->struct_size ? o->struct_size : sizeof r));
+  if (!r.zpaql_budget) r.zpaql_budget = 1ull << 32;
+  return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zpaqhip_version(void) { return ZPAQHIP_ABI_VERSION; }
+
+const char *zpaqhip_strerror(int status) { return status_message(status); }
+
+int zpaqhip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int zpaqhip_ctx_create(int device, zpaqhip_ctx **out, zpaqhip_err *err) {
+  if (!out) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
+  *out = nullptr;
+  if (!host_tables_ok()) {
+    set_err(err, ZPAQHIP_E_NO_DEVICE, -1, -1, "model tables failed their reference checksums");
+    return ZPAQHIP_E_NO_DEVICE;
+  }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+    set_err(err, ZPAQHIP_E_NO_DEVICE, -1, -1);
+    return ZPAQHIP_E_NO_DEVICE;
+  }
+  HIPCHK(hipSetDevice(device));
+  zpaqhip_ctx *c = new zpaqhip_ctx();
+  c->device = device;
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+      (e = c->tables.reserve(sizeof(ZhTables))) != hipSuccess ||
+      (e = hipMemcpy(c->tables.p, &host_tables(), sizeof(ZhTables), hipMemcpyHostToDevice)) != hipSuccess) {
+    char m[112];
+    snprintf(m, sizeof m, "HIP: %s (context setup)", hipGetErrorString(e));
+    set_err(err, ZPAQHIP_E_HIP, -1, -1, m);
+    zpaqhip_ctx_destroy(c);
+    return ZPAQHIP_E_HIP;
+  }
+  *out = c;
+  return ZPAQHIP_OK;
+}
+
+void zpaqhip_ctx_destroy(zpaqhip_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (DevBuf *b : {&c->tables, &c->arena, &c->models, &c->code, &c->bdesc, &c->sdesc, &c->results, &c->queue, &c->in, &c->out})
+    b->release();
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int zpaqhip_last_stats(const zpaqhip_ctx *c, zpaqhip_stats *out) {
+  if (!c || !out) return ZPAQHIP_E_ARG;
+  *out = c->stats;
+  return ZPAQHIP_OK;
+}
+
+int zpaqhip_scan(const uint8_t *in, size_t in_len, zpaqhip_block *blocks, size_t block_cap, size_t *n_blocks,
+                 zpaqhip_segment *segs, size_t seg_cap, size_t *n_segs, zpaqhip_err *err) {
+  if ((!in && in_len) || !n_blocks || !n_segs) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
+  ScanOut so;
+  int rc = scan_stream(in, in_len, so, err);
+  *n_blocks = so.blocks.size();
+  *n_segs = so.segs.size();
+  if (rc) return rc;
+  if (so.blocks.size() > block_cap || so.segs.size() > seg_cap) {
+    if (block_cap || seg_cap) set_err(err, ZPAQHIP_E_ARG, -1, -1, "block/segment table too small");
+    return (block_cap || seg_cap) ? ZPAQHIP_E_ARG : ZPAQHIP_OK;
+  }
+  if (blocks && !so.blocks.empty()) memcpy(blocks, so.blocks.data(), so.blocks.size() * sizeof(zpaqhip_block));
+  if (segs && !so.segs.empty()) memcpy(segs, so.segs.data(), so.segs.size() * sizeof(zpaqhip_segment));
+  return ZPAQHIP_OK;
+}
+
+int zpaqhip_read_device_tables(zpaqhip_ctx *c, uint16_t *squash, int16_t *stretch, int32_t *dt, int32_t *dt2k,
+                               uint8_t *ns, zpaqhip_err *err) {
+  if (!c) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<uint8_t> buf(sizeof(ZhTables));
+  HIPCHK(hipMemcpy(buf.data(), c->tables.p, sizeof(ZhTables), hipMemcpyDeviceToHost));
+  const ZhTables *t = reinterpret_cast<const ZhTables *>(buf.data());
+  if (squash) memcpy(squash, t->squash, sizeof t->squash);
+  if (stretch) memcpy(stretch, t->stretch, sizeof t->stretch);
+  if (dt) memcpy(dt, t->dt, sizeof t->dt);
+  if (dt2k) memcpy(dt2k, t->dt2k, sizeof t->dt2k);
+  if (ns) memcpy(ns, t->ns, sizeof t->ns);
+  return ZPAQHIP_OK;
+}
+
+// `h_hdrs`: the block headers are needed on the host to build the model
+// descriptors; they are fetched from the device stream (a few hundred bytes per
+// distinct model) so the ABI stays a pure device-buffer interface.
+int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, size_t in_len,
+                                 const zpaqhip_block *blocks,
+                                 size_t n_blocks, const zpaqhip_segment *segs, size_t n_segs, const uint32_t *ids,
+                                 size_t n_ids, void *d_out, const uint64_t *out_off, const uint64_t *out_cap,
+                                 zpaqhip_seg_result *results, const zpaqhip_opts *opts_in, void *hip_stream,
+                                 zpaqhip_err *err) {
+  if (!c || !blocks || !segs || !results || (!d_in && in_len) || (ids == nullptr && n_ids != 0 && n_ids != n_blocks)) {
+    set_err(err, ZPAQHIP_E_ARG, -1, -1);
+    return ZPAQHIP_E_ARG;
+  }
+  const zpaqhip_opts opts = resolve_opts(opts_in);
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  memset(&c->stats, 0, sizeof c->stats);
+
+  std::vector<uint32_t> sel;
+  if (ids) sel.assign(ids, ids + n_ids);
+  else { sel.resize(n_blocks); std::iota(sel.begin(), sel.end(), 0u); }
+  if (sel.empty()) return ZPAQHIP_OK;
+  for (uint32_t b : sel)
+    if (b >= n_blocks) { set_err(err, ZPAQHIP_E_ARG, (int)b, -1, "block id out of range"); return ZPAQHIP_E_ARG; }
+
+  // ---- models: one per distinct header
+  std::map<std::string, uint32_t> model_of;
+  std::vector<ZhModel> models;
+  std::vector<uint8_t> code;
+  std::vector<ZhBlockDesc> bd(sel.size());
+  std::vector<ZhSegDesc> sd(n_segs);
+  std::vector<uint8_t> hdr;
+  uint64_t stride = 256, total_in = 0, total_model = 0;
+  for (size_t k = 0; k < sel.size(); ++k) {
+    const zpaqhip_block &b = blocks[sel[k]];
+    if (b.hdr_off + b.hdr_len > in_len || (uint64_t)b.first_seg + b.n_seg > n_segs) {
+      set_err(err, ZPAQHIP_E_ARG, (int)sel[k], -1, "block table does not match the stream");
+      return ZPAQHIP_E_ARG;
+    }
+    hdr.resize(b.hdr_len);
+    if (h_in) memcpy(hdr.data(), h_in + b.hdr_off, b.hdr_len);
+    else HIPCHK(hipMemcpy(hdr.data(), (const uint8_t *)d_in + b.hdr_off, b.hdr_len, hipMemcpyDeviceToHost));
+    std::string key((const char *)hdr.data(), hdr.size());
+    auto it = model_of.find(key);
+    if (it == model_of.end()) {
+      ZhModel m;
+      int rc = build_model(hdr.data(), hdr.size(), m, code, err);
+      if (rc) { if (err) err->block = (int)sel[k]; return rc; }
+      it = model_of.emplace(key, (uint32_t)models.size()).first;
+      models.push_back(m);
+    }
+    const ZhModel &m = models[it->second];
+    stride = std::max<uint64_t>(stride, m.arena_bytes);
+    total_model += m.arena_bytes;
+    bd[k].model = it->second;
+    bd[k].first_seg = b.first_seg;
+    bd[k].n_seg = b.n_seg;
+    bd[k].out_off = out_off ? out_off[k] : 0;
+    bd[k].out_cap = out_cap ? out_cap[k] : 0;
+    for (uint32_t s = 0; s < b.n_seg; ++s) {
+      const zpaqhip_segment &sg = segs[b.first_seg + s];
+      if (sg.data_off + sg.data_len > in_len) {
+        set_err(err, ZPAQHIP_E_ARG, (int)sel[k], (int)(b.first_seg + s), "segment table does not match the stream");
+        return ZPAQHIP_E_ARG;
+      }
+      sd[b.first_seg + s].in_off = sg.data_off;
+      sd[b.first_seg + s].in_len = sg.data_len;
+      total_in += sg.data_len;
+    }
+  }
+  // Longest block first: the work queue then balances the tail (LPT order).
+  std::vector<uint32_t> order(sel.size());
+  std::iota(order.begin(), order.end(), 0u);
+  auto coded = [&](uint32_t k) {
+    uint64_t s = 0;
+    for (uint32_t i = 0; i < bd[k].n_seg; ++i) s += sd[bd[k].first_seg + i].in_len;
+    return s;
+  };
+  std::vector<uint64_t> weight(sel.size());
+  for (size_t k = 0; k < sel.size(); ++k) weight[k] = coded((uint32_t)k);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
+  std::vector<ZhBlockDesc> bd_sorted(sel.size());
+  for (size_t k = 0; k < sel.size(); ++k) bd_sorted[k] = bd[order[k]];
+
+  // ---- slots in flight
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  free_b += c->arena.cap;                               // our own cached arena is reusable
+  uint64_t budget = free_b > (1ull << 30) ? free_b - (1ull << 30) : free_b / 2;
+  uint64_t max_slots = budget / stride;
+  if (max_slots == 0) { set_err(err, ZPAQHIP_E_DEVICE_MEM, -1, -1, "Out of memory"); return ZPAQHIP_E_DEVICE_MEM; }
+  uint32_t want = opts.max_concurrent ? opts.max_concurrent : 256u;   // one wave per CU by default
+  uint32_t slots = (uint32_t)std::min<uint64_t>({(uint64_t)want, max_slots, (uint64_t)sel.size()});
+
+  HIPCHK(c->arena.reserve((size_t)slots * stride));
+  HIPCHK(c->models.reserve(models.size() * sizeof(ZhModel)));
+  HIPCHK(c->code.reserve(code.size() + 16));
+  HIPCHK(c->bdesc.reserve(bd_sorted.size() * sizeof(ZhBlockDesc)));
+  HIPCHK(c->sdesc.reserve(sd.size() * sizeof(ZhSegDesc)));
+  HIPCHK(c->results.reserve(n_segs * sizeof(ZhSegResult)));
+  HIPCHK(c->queue.reserve(256));
+  HIPCHK(hipMemcpyAsync(c->models.p, models.data(), models.size() * sizeof(ZhModel), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(c->code.p, code.data(), code.size(), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(c->bdesc.p, bd_sorted.data(), bd_sorted.size() * sizeof(ZhBlockDesc), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(c->sdesc.p, sd.data(), sd.size() * sizeof(ZhSegDesc), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemsetAsync(c->results.p, 0xff, n_segs * sizeof(ZhSegResult), stream));
+  HIPCHK(hipMemsetAsync(c->queue.p, 0, 256, stream));
+
+  ZhLaunch L;
+  memset(&L, 0, sizeof L);
+  L.in = (const uint8_t *)d_in;
+  L.models = (const ZhModel *)c->models.p;
+  L.code = (const uint8_t *)c->code.p;
+  L.blocks = (const ZhBlockDesc *)c->bdesc.p;
+  L.segs = (const ZhSegDesc *)c->sdesc.p;
+  L.results = (ZhSegResult *)c->results.p;
+  L.out = (uint8_t *)d_out;
+  L.arena = (uint8_t *)c->arena.p;
+  L.arena_stride = stride;
+  L.tables = (const ZhTables *)c->tables.p;
+  L.queue = (uint32_t *)c->queue.p;
+  L.n_blocks = (uint32_t)sel.size();
+  L.budget = opts.zpaql_budget;
+
+  HIPCHK(hipEventRecord(c->ev0, stream));
+  HIPCHK(zh_launch_generic(&L, slots, stream));
+  HIPCHK(hipEventRecord(c->ev1, stream));
+  std::vector<ZhSegResult> res(n_segs);
+  HIPCHK(hipMemcpyAsync(res.data(), c->results.p, n_segs * sizeof(ZhSegResult), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+
+  int first_bad = ZPAQHIP_OK;
+  uint64_t total_out = 0;
+  for (size_t k = 0; k < sel.size(); ++k) {
+    const zpaqhip_block &b = blocks[sel[k]];
+    for (uint32_t s = 0; s < b.n_seg; ++s) {
+      const uint32_t si = b.first_seg + s;
+      results[si].status = res[si].status;
+      results[si].pp_state = res[si].pp_state;
+      results[si].out_off = res[si].out_off;
+      results[si].out_len = res[si].out_len;
+      total_out += res[si].out_len;
+      if (res[si].status != ZPAQHIP_OK && res[si].status != ZPAQHIP_E_OUTPUT_FULL && first_bad == ZPAQHIP_OK &&
+          res[si].status != ZH_E_SKIPPED) {
+        first_bad = res[si].status;
+        set_err(err, first_bad, (int)sel[k], (int)si);
+      }
+    }
+  }
+  c->stats.kernel_ms = ms;
+  c->stats.blocks = sel.size();
+  c->stats.in_bytes = total_in;
+  c->stats.out_bytes = total_out;
+  c->stats.model_bytes = total_model;
+  c->stats.launches = 1;
+  c->stats.concurrent = slots;
+  c->stats.kernel_kind = 1;
+  return first_bad;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Whole-stream forms
+// ---------------------------------------------------------------------------
+namespace {
+
+// Decodes a host-resident stream; the plaintext ends up in ctx->out (device),
+// laid out in stream order.  Returns total plaintext length in *total.
+int decode_stream_to_device(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, const zpaqhip_opts &opts, ScanOut &so,
+                            std::vector<zpaqhip_seg_result> &res, uint64_t *total, zpaqhip_err *err) {
+  int rc = scan_stream(in, in_len, so, err);
+  if (rc) return rc;
+  *total = 0;
+  res.assign(so.segs.size(), zpaqhip_seg_result{});
+  if (so.blocks.empty()) return ZPAQHIP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(c->in.reserve(in_len + 16));
+  hipEvent_t e0 = c->ev0, e1 = c->ev1;
+  HIPCHK(hipEventRecord(e0, c->stream));
+  HIPCHK(hipMemcpyAsync(c->in.p, in, in_len, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(e1, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  float h2d = 0;
+  HIPCHK(hipEventElapsedTime(&h2d, e0, e1));
+
+  const size_t nb = so.blocks.size();
+  std::vector<uint64_t> off(nb), cap(nb);
+  // pass 1: place by the decimal sizes in the segment comments (LibZPAQ.compress
+  // writes them, LICENSE:57-58); blocks without a size are decoded in count-only mode.
+  uint64_t pos = 0;
+  bool exact_possible = true;
+  for (size_t b = 0; b < nb; ++b) {
+    uint64_t hint = so.blocks[b].usize_hint;
+    if (hint == UINT64_MAX || hint > (1ull << 40)) { hint = 0; exact_possible = false; }
+    off[b] = pos; cap[b] = hint; pos += hint;
+  }
+  HIPCHK(c->out.reserve((size_t)pos + 16));
+  rc = zpaqhip_decode_blocks_device(c, c->in.p, in, in_len, so.blocks.data(), nb, so.segs.data(), so.segs.size(), nullptr, 0,
+                                    c->out.p, off.data(), cap.data(), res.data(), &opts, c->stream, err);
+  zpaqhip_stats st1 = c->stats;
+  if (rc) return rc;
+  // did every block land exactly where the final layout wants it?
+  std::vector<uint64_t> real(nb, 0);
+  bool ok = exact_possible;
+  uint64_t pos2 = 0;
+  for (size_t b = 0; b < nb; ++b) {
+    for (uint32_t s = 0; s < so.blocks[b].n_seg; ++s) real[b] += res[so.blocks[b].first_seg + s].out_len;
+    if (real[b] != cap[b] || pos2 != off[b]) ok = false;
+    pos2 += real[b];
+  }
+  *total = pos2;
+  if (!ok) {
+    // pass 2: sizes are now known exactly; decode again into the final layout.
+    pos = 0;
+    for (size_t b = 0; b < nb; ++b) { off[b] = pos; cap[b] = real[b]; pos += real[b]; }
+    HIPCHK(c->out.reserve((size_t)pos + 16));
+    rc = zpaqhip_decode_blocks_device(c, c->in.p, in, in_len, so.blocks.data(), nb, so.segs.data(), so.segs.size(), nullptr,
+                                      0, c->out.p, off.data(), cap.data(), res.data(), &opts, c->stream, err);
+    c->stats.kernel_ms += st1.kernel_ms;
+    c->stats.launches += st1.launches;
+    if (rc) return rc;
+  }
+  c->stats.h2d_ms = h2d;
+  return ZPAQHIP_OK;
+}
+
+int verify_sha1(const ScanOut &so, const std::vector<zpaqhip_seg_result> &res, const uint8_t *out, zpaqhip_err *err) {
+  const size_t ns = so.segs.size();
+  std::vector<int> bad(ns, 0);
+  unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      for (size_t s = t; s < ns; s += nt) {
+        if (!(so.segs[s].flags & 1)) continue;
+        uint8_t d[20];
+        sha1(out + res[s].out_off, res[s].out_len, d);
+        bad[s] = memcmp(d, so.segs[s].sha1, 20) != 0;
+      }
+    });
+  for (auto &t : th) t.join();
+  for (size_t s = 0; s < ns; ++s)
+    if (bad[s]) { set_err(err, ZPAQHIP_E_SHA1, (int)so.segs[s].block, (int)s); return ZPAQHIP_E_SHA1; }
+  return ZPAQHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zpaqhip_decompress(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t *out_len,
+                       const zpaqhip_opts *opts_in, zpaqhip_err *err) {
+  if (!c || (!in && in_len) || !out_len || (!out && out_cap)) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
+  const zpaqhip_opts opts = resolve_opts(opts_in);
+  ScanOut so;
+  std::vector<zpaqhip_seg_result> res;
+  uint64_t total = 0;
+  *out_len = 0;
+  int rc = decode_stream_to_device(c, in, in_len, opts, so, res, &total, err);
+  if (rc) return rc;
+  *out_len = (size_t)total;
+  if (total > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, -1, -1); return ZPAQHIP_E_OUTPUT_FULL; }
+  if (total) {
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    HIPCHK(hipMemcpyAsync(out, c->out.p, total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->stats.d2h_ms = ms;
+  }
+  if (opts.verify_sha1) return verify_sha1(so, res, out, err);
+  return ZPAQHIP_OK;
+}
+
+int zpaqhip_decompress_cb(zpaqhip_ctx *c, zpaqhip_read_fn read_fn, zpaqhip_write_fn write_fn, void *user,
+                          const zpaqhip_opts *opts_in, zpaqhip_err *err) {
+  if (!c || !read_fn || !write_fn) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
+  const zpaqhip_opts opts = resolve_opts(opts_in);
+  std::vector<uint8_t> in;
+  for (;;) {                                            // Reader.read until EOF (Reader.cs:14-25)
+    const int chunk = 1 << 20;
+    size_t old = in.size();
+    in.resize(old + chunk);
+    int n = read_fn(user, in.data() + old, chunk);
+    if (n < 0) { set_err(err, ZPAQHIP_E_CALLBACK, -1, -1); return ZPAQHIP_E_CALLBACK; }
+    in.resize(old + (size_t)n);
+    if (n == 0) break;
+  }
+  ScanOut so;
+  std::vector<zpaqhip_seg_result> res;
+  uint64_t total = 0;
+  int rc = decode_stream_to_device(c, in.data(), in.size(), opts, so, res, &total, err);
+  if (rc) return rc;
+  std::vector<uint8_t> out((size_t)total);
+  if (total) HIPCHK(hipMemcpy(out.data(), c->out.p, total, hipMemcpyDeviceToHost));
+  if (opts.verify_sha1) { rc = verify_sha1(so, res, out.data(), err); if (rc) return rc; }
+  for (size_t p = 0; p < out.size();) {                 // Writer.write (Writer.cs:19-24)
+    int n = (int)std::min<size_t>(out.size() - p, 1 << 20);
+    if (write_fn(user, out.data() + p, n) < 0) { set_err(err, ZPAQHIP_E_CALLBACK, -1, -1); return ZPAQHIP_E_CALLBACK; }
+    p += (size_t)n;
+  }
+  return ZPAQHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// zh_host.h — internal host-side declarations of libzpaqhip.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/zpaqhip.h"
+#include "zh_model.h"
+
+namespace zh {
+
+// zh_tables.cpp — model-independent tables, generated and pinned against the
+// reference's self-check constants (Predictor.cs:71-77) and the state-table CRC.
+const ZhTables &host_tables();           // aborts the call chain via ok=false if pins fail
+bool host_tables_ok();
+
+// zh_framing.cpp
+struct ScanOut {
+  std::vector<zpaqhip_block> blocks;
+  std::vector<zpaqhip_segment> segs;
+};
+int scan_stream(const uint8_t *in, size_t n, ScanOut &out, zpaqhip_err *err);
+// Parses a stream-form header (hsize[2] hh hm ph pm n COMP 0 HCOMP 0) into a
+// ZhModel + padded code window.  Mirrors ZPAQL.read (ZPAQL.cs:112-156) and the
+// limit checks of Predictor.init (Predictor.cs:94-167).
+int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t> &code, zpaqhip_err *err);
+
+void set_err(zpaqhip_err *err, int code, int block, int seg, const char *msg = nullptr);
+
+// zh_sha1.cpp
+void sha1(const uint8_t *p, size_t n, uint8_t out[20]);
+
+}  // namespace zh

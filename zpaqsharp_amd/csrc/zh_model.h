@@ -1,0 +1,105 @@
+// zh_model.h — structures shared by the host driver and the HIP kernels.
+//
+// Data layout in HBM:
+//   stream   : the caller's compressed bytes, untouched.
+//   models   : one ZhModel per distinct block header (component table, arena map).
+//   code     : per model, the HCOMP program in a zero-padded window
+//              [ZH_CODE_PAD zeros | program | ZH_CODE_PAD zeros] so that short
+//              jumps that leave the program land on opcode 0 = error, as they do
+//              in the reference's header layout (ZPAQL.cs:112-156, 128-byte gap).
+//   arena    : one slot per block in flight; a slot holds every table of the
+//              model (cm / ht / a16 per component), the HCOMP H and M arrays,
+//              the PCOMP H and M arrays and the PCOMP program buffer.
+//   out      : plaintext, block b at out_off[b].
+#pragma once
+#include <stdint.h>
+
+enum ZhCompType : uint8_t {  // LibZPAQ.cs:51-63
+  ZH_NONE = 0, ZH_CONS = 1, ZH_CM = 2, ZH_ICM = 3, ZH_MATCH = 4, ZH_AVG = 5,
+  ZH_MIX2 = 6, ZH_MIX = 7, ZH_ISSE = 8, ZH_SSE = 9
+};
+
+#define ZH_CODE_PAD 160u          // >= 128 (max short jump) + operand bytes
+#define ZH_PCOMP_BUF (65536u + 2u * ZH_CODE_PAD)
+#define ZH_MAX_LDS_COMP 32        // component descriptors cached in LDS up to this n
+
+// Per-segment status codes written by the kernels == zpaqhip_status values.
+#define ZH_OK 0
+#define ZH_E_CORRUPT (-1)
+#define ZH_E_EOF (-2)
+#define ZH_E_EOS (-3)
+#define ZH_E_ZPAQL (-4)
+#define ZH_E_PP_EOS (-8)
+#define ZH_E_PP_TYPE (-9)
+#define ZH_E_PP_EMPTY (-10)
+#define ZH_E_OUTPUT_FULL (-20)
+#define ZH_E_BUDGET (-26)
+#define ZH_E_SKIPPED (-100)       // an earlier segment of the block failed
+
+struct ZhComp {            // one component of a model (Component.cs:18-57 + header args)
+  uint8_t type;            // ZhCompType
+  uint8_t arg[5];          // header bytes cp[1..5]
+  uint16_t pad;
+  uint32_t cm_mask;        // (#elements of cm / a16) - 1 where the reference indexes masked
+  uint32_t ht_mask;        // (#bytes of ht) - 1
+  uint64_t cm_off;         // byte offset of cm (u32[]) or a16 (u16[]) in the arena slot
+  uint64_t ht_off;         // byte offset of ht (u8[])
+  uint64_t cm_bytes;
+  uint64_t ht_bytes;
+};
+
+struct ZhModel {
+  uint32_t n;              // components
+  uint8_t hh, hm, ph, pm;
+  uint32_t code_off;       // offset of the padded HCOMP window in the code blob
+  uint32_t hcomp_len;      // program bytes incl. trailing 0
+  uint32_t kind;           // host-chosen specialisation id (0 = none)
+  uint32_t pad;
+  uint64_t h_off, m_off;   // HCOMP H (u32[1<<hh]) and M (u8[1<<hm])
+  uint64_t ph_off, pm_off; // PCOMP H and M
+  uint64_t pz_off;         // PCOMP program buffer, ZH_PCOMP_BUF bytes
+  uint64_t arena_bytes;    // slot size (multiple of 256)
+  ZhComp comp[255];
+};
+
+struct ZhBlockDesc {
+  uint32_t model;          // index into models
+  uint32_t first_seg, n_seg;
+  uint32_t pad;
+  uint64_t out_off, out_cap;
+};
+
+struct ZhSegDesc {
+  uint64_t in_off, in_len; // coded bytes of the segment within the stream
+};
+
+struct ZhSegResult {       // == zpaqhip_seg_result
+  int32_t status;
+  uint32_t pp_state;
+  uint64_t out_off, out_len;
+};
+
+struct ZhTables {          // Predictor.cs:48-79 + StateTable.cs
+  uint16_t squash[4096];
+  int16_t stretch[32768];
+  int32_t dt[1024];
+  int32_t dt2k[256];
+  uint8_t ns[1024];
+};
+
+struct ZhLaunch {          // kernel arguments (one struct, passed by value)
+  const uint8_t *in;
+  const ZhModel *models;
+  const uint8_t *code;
+  const ZhBlockDesc *blocks;
+  const ZhSegDesc *segs;
+  ZhSegResult *results;
+  uint8_t *out;
+  uint8_t *arena;
+  uint64_t arena_stride;
+  const ZhTables *tables;
+  uint32_t *queue;         // work-queue head (device-scope atomic)
+  uint32_t n_blocks;
+  uint32_t pad;
+  uint64_t budget;         // ZPAQL instructions per run()
+};
