@@ -16,9 +16,39 @@
 
 namespace zh {
 
+const char *status_message(int code) {
+  switch (code) {
+    case ZPAQHIP_OK: return "ok";
+    case ZPAQHIP_E_CORRUPT: return "archive corrupted";
+    case ZPAQHIP_E_EOF: return "unexpected end of file";
+    case ZPAQHIP_E_EOS: return "decoding end of stream";
+    case ZPAQHIP_E_ZPAQL: return "ZPAQL execution error";
+    case ZPAQHIP_E_HEADER: return "invalid block header";
+    case ZPAQHIP_E_HM_TOO_BIG: return "H too big";
+    case ZPAQHIP_E_COMPONENT: return "invalid component";
+    case ZPAQHIP_E_PP_EOS: return "Unexpected EOS";
+    case ZPAQHIP_E_PP_TYPE: return "unknown post processing type";
+    case ZPAQHIP_E_PP_EMPTY: return "Empty PCOMP";
+    case ZPAQHIP_E_LEVEL: return "unsupported ZPAQ level";
+    case ZPAQHIP_E_SEGMENT: return "missing segment or end of block";
+    case ZPAQHIP_E_FRAMING_EOF: return "unexpected EOF";
+    case ZPAQHIP_E_RESERVED: return "missing reserved byte";
+    case ZPAQHIP_E_SEGEND: return "missing end of segment marker";
+    case ZPAQHIP_E_OUTPUT_FULL: return "output buffer too small";
+    case ZPAQHIP_E_SHA1: return "SHA-1 checksum mismatch";
+    case ZPAQHIP_E_NO_DEVICE: return "no usable HIP device";
+    case ZPAQHIP_E_DEVICE_MEM: return "Out of memory";
+    case ZPAQHIP_E_HIP: return "HIP runtime error";
+    case ZPAQHIP_E_ARG: return "bad argument";
+    case ZPAQHIP_E_BUDGET: return "ZPAQL instruction budget exhausted";
+    case ZPAQHIP_E_CALLBACK: return "read/write callback failed";
+    case ZH_E_SKIPPED: return "segment skipped after an earlier error in its block";
+    default: return "unknown status";
+  }
+}
+
 static const int kCompSize[10] = {0, 2, 3, 2, 3, 4, 6, 6, 3, 5};   // Component.cs:27-43
 
-const char *status_message(int code);
 
 void set_err(zpaqhip_err *err, int code, int block, int seg, const char *msg) {
   if (!err) return;

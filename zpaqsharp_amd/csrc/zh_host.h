@@ -27,6 +27,7 @@ int scan_stream(const uint8_t *in, size_t n, ScanOut &out, zpaqhip_err *err);
 // limit checks of Predictor.init (Predictor.cs:94-167).
 int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t> &code, zpaqhip_err *err);
 
+const char *status_message(int code);
 void set_err(zpaqhip_err *err, int code, int block, int seg, const char *msg = nullptr);
 
 // zh_sha1.cpp
