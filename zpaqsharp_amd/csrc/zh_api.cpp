@@ -18,6 +18,7 @@
 #include "zh_host.h"
 
 extern "C" hipError_t zh_launch_generic(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
+extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream);
 
 
 using namespace zh;
@@ -43,7 +44,7 @@ struct zpaqhip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  DevBuf tables, arena, models, code, bdesc, sdesc, results, queue, in, out;
+  DevBuf tables, fused, arena, models, code, bdesc, sdesc, results, queue, in, out;
   zpaqhip_stats stats{};
 };
 
@@ -108,6 +109,19 @@ int zpaqhip_ctx_create(int device, zpaqhip_ctx **out, zpaqhip_err *err) {
     zpaqhip_ctx_destroy(c);
     return ZPAQHIP_E_HIP;
   }
+  {  // fused squash(stretch(x))*2+1 table for single-CM models (zh_cm.hip)
+    const ZhTables &t = host_tables();
+    std::vector<uint16_t> fused(32768);
+    for (int x = 0; x < 32768; ++x) fused[x] = (uint16_t)(t.squash[t.stretch[x] + 2048] * 2 + 1);
+    if ((e = c->fused.reserve(65536)) != hipSuccess ||
+        (e = hipMemcpy(c->fused.p, fused.data(), 65536, hipMemcpyHostToDevice)) != hipSuccess) {
+      char m[112];
+      snprintf(m, sizeof m, "HIP: %s (context setup)", hipGetErrorString(e));
+      set_err(err, ZPAQHIP_E_HIP, -1, -1, m);
+      zpaqhip_ctx_destroy(c);
+      return ZPAQHIP_E_HIP;
+    }
+  }
   *out = c;
   return ZPAQHIP_OK;
 }
@@ -115,7 +129,7 @@ int zpaqhip_ctx_create(int device, zpaqhip_ctx **out, zpaqhip_err *err) {
 void zpaqhip_ctx_destroy(zpaqhip_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (DevBuf *b : {&c->tables, &c->arena, &c->models, &c->code, &c->bdesc, &c->sdesc, &c->results, &c->queue, &c->in, &c->out})
+  for (DevBuf *b : {&c->tables, &c->fused, &c->arena, &c->models, &c->code, &c->bdesc, &c->sdesc, &c->results, &c->queue, &c->in, &c->out})
     b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -193,7 +207,7 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
   std::vector<ZhBlockDesc> bd(sel.size());
   std::vector<ZhSegDesc> sd(n_segs);
   std::vector<uint8_t> hdr;
-  uint64_t stride = 256, total_in = 0, total_model = 0;
+  uint64_t total_in = 0, total_model = 0;
   for (size_t k = 0; k < sel.size(); ++k) {
     const zpaqhip_block &b = blocks[sel[k]];
     if (b.hdr_off + b.hdr_len > in_len || (uint64_t)b.first_seg + b.n_seg > n_segs) {
@@ -213,7 +227,6 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
       models.push_back(m);
     }
     const ZhModel &m = models[it->second];
-    stride = std::max<uint64_t>(stride, m.arena_bytes);
     total_model += m.arena_bytes;
     bd[k].model = it->second;
     bd[k].first_seg = b.first_seg;
@@ -231,62 +244,85 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
       total_in += sg.data_len;
     }
   }
-  // Longest block first: the work queue then balances the tail (LPT order).
-  std::vector<uint32_t> order(sel.size());
-  std::iota(order.begin(), order.end(), 0u);
-  auto coded = [&](uint32_t k) {
-    uint64_t s = 0;
-    for (uint32_t i = 0; i < bd[k].n_seg; ++i) s += sd[bd[k].first_seg + i].in_len;
-    return s;
-  };
-  std::vector<uint64_t> weight(sel.size());
-  for (size_t k = 0; k < sel.size(); ++k) weight[k] = coded((uint32_t)k);
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
-  std::vector<ZhBlockDesc> bd_sorted(sel.size());
-  for (size_t k = 0; k < sel.size(); ++k) bd_sorted[k] = bd[order[k]];
+  std::vector<uint64_t> weight(sel.size(), 0);
+  for (size_t k = 0; k < sel.size(); ++k)
+    for (uint32_t i = 0; i < bd[k].n_seg; ++i) weight[k] += sd[bd[k].first_seg + i].in_len;
 
-  // ---- slots in flight
+  // ---- kernel family per block (opts.kernel == 1 forces the generic kernel)
+  auto family = [&](size_t k) -> uint32_t {
+    return opts.kernel == 1 ? ZH_FAM_GENERIC : (models[bd[k].model].kind & 255u);
+  };
+  std::vector<std::vector<uint32_t>> groups(2);
+  for (size_t k = 0; k < sel.size(); ++k) groups[family(k)].push_back((uint32_t)k);
+
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
   free_b += c->arena.cap;                               // our own cached arena is reusable
-  uint64_t budget = free_b > (1ull << 30) ? free_b - (1ull << 30) : free_b / 2;
-  uint64_t max_slots = budget / stride;
-  if (max_slots == 0) { set_err(err, ZPAQHIP_E_DEVICE_MEM, -1, -1, "Out of memory"); return ZPAQHIP_E_DEVICE_MEM; }
-  uint32_t want = opts.max_concurrent ? opts.max_concurrent : 256u;   // one wave per CU by default
-  uint32_t slots = (uint32_t)std::min<uint64_t>({(uint64_t)want, max_slots, (uint64_t)sel.size()});
+  const uint64_t mem_budget = free_b > (1ull << 30) ? free_b - (1ull << 30) : free_b / 2;
 
-  HIPCHK(c->arena.reserve((size_t)slots * stride));
   HIPCHK(c->models.reserve(models.size() * sizeof(ZhModel)));
   HIPCHK(c->code.reserve(code.size() + 16));
-  HIPCHK(c->bdesc.reserve(bd_sorted.size() * sizeof(ZhBlockDesc)));
+  HIPCHK(c->bdesc.reserve(sel.size() * sizeof(ZhBlockDesc)));
   HIPCHK(c->sdesc.reserve(sd.size() * sizeof(ZhSegDesc)));
   HIPCHK(c->results.reserve(n_segs * sizeof(ZhSegResult)));
   HIPCHK(c->queue.reserve(256));
   HIPCHK(hipMemcpyAsync(c->models.p, models.data(), models.size() * sizeof(ZhModel), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(c->code.p, code.data(), code.size(), hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemcpyAsync(c->bdesc.p, bd_sorted.data(), bd_sorted.size() * sizeof(ZhBlockDesc), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(c->sdesc.p, sd.data(), sd.size() * sizeof(ZhSegDesc), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemsetAsync(c->results.p, 0xff, n_segs * sizeof(ZhSegResult), stream));
   HIPCHK(hipMemsetAsync(c->queue.p, 0, 256, stream));
 
-  ZhLaunch L;
-  memset(&L, 0, sizeof L);
-  L.in = (const uint8_t *)d_in;
-  L.models = (const ZhModel *)c->models.p;
-  L.code = (const uint8_t *)c->code.p;
-  L.blocks = (const ZhBlockDesc *)c->bdesc.p;
-  L.segs = (const ZhSegDesc *)c->sdesc.p;
-  L.results = (ZhSegResult *)c->results.p;
-  L.out = (uint8_t *)d_out;
-  L.arena = (uint8_t *)c->arena.p;
-  L.arena_stride = stride;
-  L.tables = (const ZhTables *)c->tables.p;
-  L.queue = (uint32_t *)c->queue.p;
-  L.n_blocks = (uint32_t)sel.size();
-  L.budget = opts.zpaql_budget;
+  // arena: sized for the most demanding group
+  uint32_t slots_of[2] = {0, 0};
+  uint64_t stride_of[2] = {256, 256}, arena_need = 0;
+  for (uint32_t g = 0; g < 2; ++g) {
+    if (groups[g].empty()) continue;
+    for (uint32_t k : groups[g]) stride_of[g] = std::max<uint64_t>(stride_of[g], models[bd[k].model].arena_bytes);
+    uint64_t max_slots = mem_budget / stride_of[g];
+    if (max_slots == 0) { set_err(err, ZPAQHIP_E_DEVICE_MEM, -1, -1, "Out of memory"); return ZPAQHIP_E_DEVICE_MEM; }
+    uint32_t want = opts.max_concurrent ? opts.max_concurrent : 256u;   // one wave per CU by default
+    slots_of[g] = (uint32_t)std::min<uint64_t>({(uint64_t)want, max_slots, (uint64_t)groups[g].size()});
+    arena_need = std::max<uint64_t>(arena_need, slots_of[g] * stride_of[g]);
+  }
+  HIPCHK(c->arena.reserve((size_t)arena_need));
 
+  std::vector<ZhBlockDesc> bd_sorted;
+  bd_sorted.reserve(sel.size());
+  size_t base_of[2] = {0, 0};
+  for (uint32_t g = 0; g < 2; ++g) {
+    // Longest block first: the work queue then balances the tail (LPT order).
+    std::stable_sort(groups[g].begin(), groups[g].end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
+    base_of[g] = bd_sorted.size();
+    for (uint32_t k : groups[g]) bd_sorted.push_back(bd[k]);
+  }
+  HIPCHK(hipMemcpyAsync(c->bdesc.p, bd_sorted.data(), bd_sorted.size() * sizeof(ZhBlockDesc), hipMemcpyHostToDevice, stream));
+
+  uint32_t launches = 0, slots = 0, kind_used = 0;
   HIPCHK(hipEventRecord(c->ev0, stream));
-  HIPCHK(zh_launch_generic(&L, slots, stream));
+  for (uint32_t g = 0; g < 2; ++g) {
+    if (groups[g].empty()) continue;
+    ZhLaunch L;
+    memset(&L, 0, sizeof L);
+    L.in = (const uint8_t *)d_in;
+    L.in_total = in_len;
+    L.models = (const ZhModel *)c->models.p;
+    L.code = (const uint8_t *)c->code.p;
+    L.blocks = (const ZhBlockDesc *)c->bdesc.p + base_of[g];
+    L.segs = (const ZhSegDesc *)c->sdesc.p;
+    L.results = (ZhSegResult *)c->results.p;
+    L.out = (uint8_t *)d_out;
+    L.arena = (uint8_t *)c->arena.p;
+    L.arena_stride = stride_of[g];
+    L.tables = (const ZhTables *)c->tables.p;
+    L.queue = (uint32_t *)c->queue.p + 16 * g;          // one work-queue head per launch
+    L.n_blocks = (uint32_t)groups[g].size();
+    L.budget = opts.zpaql_budget;
+    if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, (const uint16_t *)c->fused.p, slots_of[g], stream));
+    else HIPCHK(zh_launch_generic(&L, slots_of[g], stream));
+    ++launches;
+    slots = std::max(slots, slots_of[g]);
+    kind_used = std::max(kind_used, g + 1);
+  }
   HIPCHK(hipEventRecord(c->ev1, stream));
   std::vector<ZhSegResult> res(n_segs);
   HIPCHK(hipMemcpyAsync(res.data(), c->results.p, n_segs * sizeof(ZhSegResult), hipMemcpyDeviceToHost, stream));
@@ -317,9 +353,9 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
   c->stats.in_bytes = total_in;
   c->stats.out_bytes = total_out;
   c->stats.model_bytes = total_model;
-  c->stats.launches = 1;
+  c->stats.launches = launches;
   c->stats.concurrent = slots;
-  c->stats.kernel_kind = 1;
+  c->stats.kernel_kind = kind_used;
   return first_bad;
 }
 

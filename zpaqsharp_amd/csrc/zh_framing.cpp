@@ -345,6 +345,14 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
   code.insert(code.end(), hdr + cp, hdr + len);
   code.insert(code.end(), ZH_CODE_PAD, 0);
   while (code.size() & 15) code.push_back(0);
+  // ---- specialisation the kernels may use (never changes results)
+  m.kind = ZH_FAM_GENERIC;
+  if (m.n == 1 && m.comp[0].type == ZH_CM && m.comp[0].arg[0] >= 9) {
+    m.kind = ZH_FAM_CM1;
+    const uint8_t *hc = hdr + cp;                       // "a<<= K  *d=a  halt" (D is 0 at every entry)
+    if (m.hcomp_len == 5 && hc[0] == 207 && hc[2] == 112 && hc[3] == 56 && hc[4] == 0)
+      m.kind |= ZH_HK_SHIFT << 8 | (uint32_t)(hc[1] & 31) << 16;
+  }
   return ZPAQHIP_OK;
 }
 

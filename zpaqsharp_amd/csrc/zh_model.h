@@ -23,6 +23,11 @@ enum ZhCompType : uint8_t {  // LibZPAQ.cs:51-63
 #define ZH_PCOMP_BUF (65536u + 2u * ZH_CODE_PAD)
 #define ZH_MAX_LDS_COMP 32        // component descriptors cached in LDS up to this n
 
+#define ZH_FAM_GENERIC 0u        // zh_generic.hip
+#define ZH_FAM_CM1 1u            // zh_cm.hip: n == 1, one CM with >= 9 size bits
+#define ZH_HK_GENERIC 0u         // interpret HCOMP
+#define ZH_HK_SHIFT 1u           // HCOMP == "a<<= K  *d=a  halt" with D == 0: H[0] = c << K
+
 // Per-segment status codes written by the kernels == zpaqhip_status values.
 #define ZH_OK 0
 #define ZH_E_CORRUPT (-1)
@@ -53,7 +58,8 @@ struct ZhModel {
   uint8_t hh, hm, ph, pm;
   uint32_t code_off;       // offset of the padded HCOMP window in the code blob
   uint32_t hcomp_len;      // program bytes incl. trailing 0
-  uint32_t kind;           // host-chosen specialisation id (0 = none)
+  uint32_t kind;           // host-chosen specialisation: bits 0-7 kernel family (ZH_FAM_*),
+                           // bits 8-15 HCOMP form (ZH_HK_*), bits 16-23 its parameter
   uint32_t pad;
   uint64_t h_off, m_off;   // HCOMP H (u32[1<<hh]) and M (u8[1<<hm])
   uint64_t ph_off, pm_off; // PCOMP H and M
@@ -102,4 +108,5 @@ struct ZhLaunch {          // kernel arguments (one struct, passed by value)
   uint32_t n_blocks;
   uint32_t pad;
   uint64_t budget;         // ZPAQL instructions per run()
+  uint64_t in_total;       // length of the whole stream at `in`
 };
