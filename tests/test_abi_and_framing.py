@@ -1,0 +1,125 @@
+"""C ABI surface (include/zpaqhip.h) and the host-side framing scan; no GPU needed."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+import oracle
+import zpaqsharp_amd as z
+from tests import util
+from zpaqsharp_amd import _lib, models
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "zpaqhip.h")).read()
+    declared = set(re.findall(r"\b(zpaqhip_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS)
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert z.version() == 1
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    # sizeof as the C compiler sees include/zpaqhip.h vs the ctypes mirrors
+    names = ["err", "block", "segment", "seg_result", "opts", "stats"]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "zpaqhip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   + ",".join(f"sizeof(zpaqhip_{n})" for n in names) + ");return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    mirrors = [_lib.Err, _lib.Block, _lib.Segment, _lib.SegResult, _lib.Opts, _lib.Stats]
+    assert got == [C.sizeof(m) for m in mirrors]
+
+
+def test_status_messages_use_reference_wording():
+    assert z.strerror(-1) == "archive corrupted"            # Decoder.cs:141
+    assert z.strerror(-2) == "unexpected end of file"       # Decoder.cs:154
+    assert z.strerror(-3) == "decoding end of stream"       # Decoder.cs:43
+    assert z.strerror(-4) == "ZPAQL execution error"        # ZPAQL.cs:1316
+    assert z.strerror(-8) == "Unexpected EOS"               # PostProcessor.cs:43
+    assert z.strerror(-15) == "missing end of segment marker"
+
+
+@pytest.mark.skipif(z.device_count() > 0, reason="this check is for GPU-less machines")
+def test_no_cpu_fallback_without_a_gpu():
+    with pytest.raises(z.ZpaqError) as e:
+        z.Context(0)
+    assert e.value.code == -22                              # ZPAQHIP_E_NO_DEVICE
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "zpaqsharp_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "zpaq_oracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+def _stream():
+    parts, meta = [], []
+    for i, (model, n) in enumerate([("l1", 5000), ("mid", 0), ("max+e8e9", 1500), ("min", 4097)]):
+        d = util.x86ish(n, i) if "e8e9" in model else util.text(n, i)
+        parts.append(util.block(model, d, filename=b"f%d" % i))
+        meta.append((model, d))
+    return b"garbage" + parts[0] + parts[1] + b"\0\0\0" + parts[2] + parts[3] + b"tail", meta
+
+
+def test_scan_agrees_with_the_decompresser_state_machine():
+    s, meta = _stream()
+    sc = z.scan(s)
+    assert sc.n_blocks == 4 and sc.n_segments == 4
+    d = oracle.Decompresser(s)
+    for b, (model, data) in zip(sc.blocks, meta):
+        mem = d.find_block()
+        assert mem == b.model_mem                              # ZPAQL.memory(), ZPAQL.cs:58-81
+        hdr = models.get(model).header
+        assert s[b.hdr_off:b.hdr_off + b.hdr_len] == hdr and b.n_comp == hdr[6]
+        g = sc.segments[b.first_seg]
+        assert d.find_filename() == s[g.name_off:g.name_off + g.name_len]
+        assert d.read_comment() == s[g.comment_off:g.comment_off + g.comment_len] == str(len(data)).encode()
+        assert d.tell() == g.data_off
+        assert d.decompress(cap=len(data) + 16)[0] == data
+        assert d.tell() == g.data_off + g.data_len            # coded bytes incl. the terminating zeros
+        assert d.read_segment_end() == bytes(g.sha1) and g.flags == 1
+        assert g.usize_hint == len(data) == b.usize_hint
+        assert d.find_filename() is None and d.tell() == b.end_off
+    assert d.find_block() is None
+
+
+def test_scan_skipping_equals_decoder_skip():
+    # readSegmentEnd without decompress() uses Decoder.skip (Decoder.cs:70-98)
+    s, _ = _stream()
+    sc = z.scan(s)
+    d = oracle.Decompresser(s)
+    for b in sc.blocks:
+        d.find_block(); d.find_filename(); d.read_comment()
+        g = sc.segments[b.first_seg]
+        assert d.read_segment_end() == bytes(g.sha1)
+        assert d.find_filename() is None and d.tell() == b.end_off
+
+
+@pytest.mark.parametrize("mutate,code,msg", [
+    (lambda s: s[:13] + b"zPQ\x03" + s[17:], -11, "unsupported ZPAQ level"),
+    (lambda s: s[:13] + b"zPQ\x01\x02" + s[18:], -11, "unsupported ZPAQL type"),
+    (lambda s: s[:40], -2, "unexpected end of file"),
+    (lambda s: s[:-22] + b"\x07" + s[-21:], -15, "missing end of segment marker"),
+    (lambda s: s[:-1] + b"\x09", -12, "missing segment or end of block"),
+])
+def test_scan_errors_match_the_oracle(mutate, code, msg):
+    s = mutate(util.block("mid", util.text(500)))
+    with pytest.raises(z.ZpaqError) as e:
+        z.scan(s)
+    assert e.value.code == code and msg in str(e.value)
+    with pytest.raises(oracle.OracleError, match=msg):
+        oracle.decompress(s)
+
+
+def test_scan_of_empty_and_tagless_input():
+    assert z.scan(b"").n_blocks == 0
+    assert z.scan(b"no zpaq here" * 100).n_blocks == 0

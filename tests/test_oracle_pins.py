@@ -1,0 +1,221 @@
+"""Pins the CPU oracle against every constant / known answer the reference carries
+(SURVEY.md §4, §8c).  The reference has no tests or vectors of its own; tests
+marked `reference` read its source as text and are skipped where it is absent."""
+import hashlib
+import json
+import math
+import os
+import re
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import util
+from tests.conftest import REFERENCE
+from zpaqsharp_amd import models, zpaql
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TAG = bytes([0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3])
+
+
+def _ref(name):
+    with open(os.path.join(REFERENCE, name), encoding="utf-8-sig") as f:
+        return f.read()
+
+
+def _ints(src, name):
+    m = re.search(name + r"[^{;]*\{([^}]*)\}", src, re.S)
+    return [int(x) for x in re.findall(r"-?\d+", m.group(1))]
+
+
+# ---- constants quoted from the reference (Predictor.cs:71-77) -------------
+def test_table_self_check_constants():
+    stsum, sqsum, sns = oracle.table_pins()
+    assert stsum == 3887533746 and sqsum == 2278286169      # Predictor.cs:76-77
+    assert sns == 0x77A1E24C                                # CRC-32 of StateTable.cs:21-149
+
+
+def test_tables_follow_their_generator_formulas():
+    sq, st, dt, dt2k, ns = oracle.tables()
+    # Predictor.cs:54,60,1358,1394 generator comments
+    assert dt2k[0] == 0 and all(dt2k[i] == 2048 // i for i in range(1, 256))
+    assert all(dt[i] == (1 << 17) // (i * 2 + 3) * 2 for i in range(1024))
+    assert all(sq[i] == 0 for i in range(1376)) and all(sq[i] == 32767 for i in range(2720, 4096))
+    for i in range(1376, 2720):
+        assert sq[i] == int(32768.0 / (1 + math.exp((i - 2048) * (-1.0 / 64))))
+    assert all(st[i] == -st[32767 - i] for i in range(16384))
+    assert st.min() == -710 and st.max() == 710
+    assert np.all(np.diff(st.astype(int)) >= 0)
+    assert zlib.crc32(ns.tobytes()) == 0x77A1E24C
+
+
+def test_tag_locator_hash_matches_findblock_targets():
+    # Decompresser.cs:34,43: the four rolling hashes hit these targets after tag + "zPQ"
+    assert oracle.tag_hash(TAG + b"zPQ") == (0xB16B88F1, 0xFF5376F1, 0x72AC5BF1, 0x2F909AF1)
+    # and they are true 16-byte window hashes: any prefix before the locator is forgotten
+    assert oracle.tag_hash(b"x" * 37 + TAG + b"zPQ") == (0xB16B88F1, 0xFF5376F1, 0x72AC5BF1, 0x2F909AF1)
+
+
+def test_builtin_models_parse_to_the_documented_shapes():
+    # Compressor.cs:48-74: hsize 26 / 69 / 196, n = 2 / 8 / 22
+    for name, hsize, n, hh, hm in (("min", 26, 2, 1, 2), ("mid", 69, 8, 3, 3), ("max", 196, 22, 5, 9)):
+        m = models.get(name)
+        assert m.header[0] + 256 * m.header[1] == hsize and m.n == n
+        p = zpaql.parse_header(m.header)
+        assert p[0] == hh and p[1] == hm
+        assert zpaql.assemble(zpaql.disassemble(m.header)).header == m.header
+    l1 = models.get("l1").header
+    assert l1.hex() == "0e000000000001021 1ff00cf09703800".replace(" ", "")      # SURVEY §8d L1 header bytes
+
+
+# ---- cross-checks against the reference text itself ---------------------------------
+@pytest.mark.reference
+def test_state_table_equals_reference_text():
+    sns = _ints(_ref("StateTable.cs"), "sns")
+    assert len(sns) == 1024 and list(oracle.tables()[4]) == sns
+
+
+@pytest.mark.reference
+def test_numeric_tables_equal_reference_text():
+    src = _ref("Predictor.cs")
+    sq, st, dt, dt2k, _ = oracle.tables()
+    assert list(sq[1376:2720]) == _ints(src, "ssquasht")
+    stdt = _ints(src, "stdt")
+    k, s2 = 16384, np.zeros(32768, int)
+    for i, n in enumerate(stdt):
+        s2[k:k + n] = i
+        k += n
+    s2[:16384] = -s2[32767:16383:-1]
+    assert k == 32768 and np.array_equal(s2, st.astype(int))
+    assert list(dt) == _ints(src, r"\bsdt\b") and list(dt2k) == _ints(src, "sdt2k")
+
+
+@pytest.mark.reference
+def test_model_bytecodes_equal_reference_text():
+    src = _ref("Compressor.cs")
+    body = re.sub(r"//[^\n]*", "", re.search(r"models\[\]\s*=\s*\{(.*?)\};", src, re.S).group(1))
+    vals = [int(a or b) & 255 for a, b in re.findall(r"\(char\)(-?\d+)|(-?\d+)", body)]
+    p, got = 0, []
+    while vals[p] + 256 * vals[p + 1]:
+        n = vals[p] + 256 * vals[p + 1]
+        got.append(bytes(vals[p:p + n + 2]))
+        p += n + 2
+    assert got == [models.get(n).header for n in ("min", "mid", "max")]
+
+
+@pytest.mark.reference
+def test_tag_bytes_and_hash_constants_equal_reference_text():
+    comp, dec = _ref("Compressor.cs"), _ref("Decompresser.cs")
+    tag = bytes(int(x, 16) for x in re.findall(r"put\(0x([0-9a-fA-F]{2})\)", comp)[:13])
+    assert tag == TAG
+    consts = [int(x, 16) for x in re.findall(r"0x([0-9A-Fa-f]{8})", dec)]
+    assert consts[:4] == [0x3D49B113, 0x29EB7F93, 0x2614BE13, 0x3828EB13]
+    assert tuple(consts[4:8]) == oracle.tag_hash(TAG + b"zPQ")
+    # the start constants are the hash state after the first 13 bytes of ... zero history:
+    assert oracle.tag_hash(b"") == tuple(consts[:4])
+
+
+# ---- golden fixtures ------------------------------------------------------------------
+def _manifest():
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", sorted(_manifest()))
+def test_oracle_reproduces_golden(name):
+    e = _manifest()[name]
+    stream = open(os.path.join(GOLD, name + ".zpaq"), "rb").read()
+    assert hashlib.sha1(stream).hexdigest() == e["stream_sha1"]
+    d = oracle.Decompresser(stream)
+    d.set_trace()
+    assert d.find_block() is not None and d.find_filename() == b""
+    assert d.read_comment() == str(e["plain_len"]).encode()
+    out, more = d.decompress(-1, cap=e["plain_len"] + 16)
+    assert not more and hashlib.sha1(out).hexdigest() == e["plain_sha1"]
+    assert d.read_segment_end() == bytes.fromhex(e["plain_sha1"])       # in-stream SHA-1, Decompresser.cs:183-191
+    assert d.trace() == e["trace_crc32_per_4096_bits"]
+    assert list(d.state()) == e["final_state_low_high_curr_c8_hmap4_h0_h1_h2"]
+    assert d.hcomp() == bytes.fromhex(e["header_hex"])
+    assert d.find_filename() is None and d.find_block() is None
+
+
+# ---- behaviour -------------------------------------------------------------------------
+@pytest.mark.parametrize("model", ["l1", "min", "mid", "max", "max+e8e9"])
+def test_round_trip_and_partial_decode(model):
+    data = util.x86ish(5000) if "e8e9" in model else util.text(5000)
+    s = util.block(model, data)
+    assert oracle.decompress(s) == data
+    d = oracle.Decompresser(s)
+    d.find_block(), d.find_filename(), d.read_comment()
+    got = b""
+    while True:                                   # decompress(n) is resumable (Decompresser.cs:121,141-152)
+        part, more = d.decompress(777, cap=6000)
+        got += part
+        if not more:
+            break
+    assert got == data
+
+
+def test_multi_segment_block_shares_model_state():
+    m = models.get("mid")
+    a, b = util.text(3000, 1), util.text(2000, 2)
+    c = oracle.Compressor(20000)
+    c.write_tag(); c.start_block(m.header)
+    c.start_segment(b"a.txt", b"3000"); c.post_process(); c.compress(a); c.end_segment(oracle.sha1(a))
+    c.start_segment(b"b.txt", b"2000"); c.compress(b); c.end_segment(None)
+    c.end_block()
+    s = c.getvalue()
+    d = oracle.Decompresser(s)
+    assert d.find_block() is not None
+    assert d.find_filename() == b"a.txt" and d.read_comment() == b"3000"
+    assert d.decompress()[0] == a and d.read_segment_end() == oracle.sha1(a)
+    assert d.find_filename() == b"b.txt" and d.read_comment() == b"2000"
+    assert d.decompress()[0] == b and d.read_segment_end() is None
+    assert d.find_filename() is None
+    # second segment is smaller than a fresh block would be: the model carried over
+    assert len(s) < len(util.block("mid", a)) + len(util.block("mid", b))
+    assert oracle.decompress(s) == a + b
+
+
+def test_unmodelled_store_block():
+    # n = 0: level-2 block, data stored as [len32 BE, bytes]*, 0 (Decoder.cs:58-67)
+    hdr = zpaql.assemble("comp 0 0 0 0 0 hcomp halt end").header
+    payload = b"\0hello world" + bytes(range(200))             # leading 0 = PASS
+    body = len(payload).to_bytes(4, "big") + payload + b"\0\0\0\0"
+    s = TAG + b"zPQ" + bytes([2, 1]) + hdr + b"\x01\0\0\0" + body + bytes([254, 255])
+    assert oracle.decompress(s) == payload[1:]
+
+
+def test_e8e9_pcomp_inverts_forward_transform():
+    pc = models.get("max+e8e9").pcomp
+    rng = np.random.default_rng(3)
+    for n in list(range(0, 12)) + [100, 4096]:
+        x = bytearray(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+        for i in range(0, max(0, n - 5), 11):
+            x[i], x[i + 4] = (0xE8, 0x00) if i % 2 else (0xE9, 0xFF)
+        x = bytes(x)
+        assert oracle.run_pcomp(pc, oracle.e8e9(x), 0, 3) == x
+
+
+@pytest.mark.parametrize("mutate,msg", [
+    (lambda s: s[:40], "unexpected end of file"),                      # cut inside the header
+    (lambda s: s[:13] + b"zPQ\x03" + s[17:], "unsupported ZPAQ level"),
+    (lambda s: s[:13] + b"zPQ\x01\x02" + s[18:], "unsupported ZPAQL type"),
+    (lambda s: s[:-22] + b"\x07" + s[-21:], "missing end of segment marker"),
+])
+def test_framing_errors(mutate, msg):
+    s = util.block("mid", util.text(500))
+    with pytest.raises(oracle.OracleError, match=msg):
+        oracle.decompress(mutate(s))
+
+
+def test_zpaql_errors():
+    bad = bytes([0]) + b"\0"                                   # opcode 0 = error
+    with pytest.raises(oracle.OracleError):
+        oracle.run_pcomp(bad, b"x")
+    jump_out = bytes([63, 100, 0])                             # jmp +100: lands in the zero guard
+    with pytest.raises(oracle.OracleError):
+        oracle.run_pcomp(jump_out, b"x")
+    assert oracle.run_pcomp(bytes([57, 56, 0]), b"abc") == b"abc\xff"   # out halt: echoes input, then EOF low byte

@@ -6,6 +6,7 @@
 // GPU fails with ZPAQHIP_E_NO_DEVICE when none is usable.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -19,6 +20,7 @@
 
 extern "C" hipError_t zh_launch_generic(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream);
+extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream);
 
 
 using namespace zh;
@@ -317,13 +319,24 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     L.queue = (uint32_t *)c->queue.p + 16 * g;          // one work-queue head per launch
     L.n_blocks = (uint32_t)groups[g].size();
     L.budget = opts.zpaql_budget;
-    if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, (const uint16_t *)c->fused.p, slots_of[g], stream));
+    const bool prof = getenv("ZPAQHIP_PROF") != nullptr;   // diagnostic build with in-kernel stamps
+    if (prof) { L.debug = (uint64_t *)c->queue.p + 16; HIPCHK(hipMemsetAsync(L.debug, 0, 64, stream)); }
+    if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, (const uint16_t *)c->fused.p, slots_of[g], stream));
+    else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, (const uint16_t *)c->fused.p, slots_of[g], stream));
     else HIPCHK(zh_launch_generic(&L, slots_of[g], stream));
     ++launches;
     slots = std::max(slots, slots_of[g]);
     kind_used = std::max(kind_used, g + 1);
   }
   HIPCHK(hipEventRecord(c->ev1, stream));
+  if (getenv("ZPAQHIP_PROF")) {
+    uint64_t dbg[8];
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipMemcpy(dbg, (uint64_t *)c->queue.p + 16, 64, hipMemcpyDeviceToHost));
+    fprintf(stderr, "ZPAQHIP_PROF cycles:");
+    for (int i = 0; i < 8; ++i) fprintf(stderr, " %llu", (unsigned long long)dbg[i]);
+    fprintf(stderr, "\n");
+  }
   std::vector<ZhSegResult> res(n_segs);
   HIPCHK(hipMemcpyAsync(res.data(), c->results.p, n_segs * sizeof(ZhSegResult), hipMemcpyDeviceToHost, stream));
   HIPCHK(hipStreamSynchronize(stream));

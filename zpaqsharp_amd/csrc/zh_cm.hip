@@ -183,8 +183,24 @@ __device__ uint32_t win_get(uint32_t w, uint32_t &tag, uint32_t &stamp, uint32_t
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(64) void zh_decode_cm(ZhLaunch L, const uint16_t *__restrict__ fused_g) {
-  __shared__ CmLds S;
+// In-kernel stamps (diagnostic build only: zh_decode_cm_prof): cycles spent per
+// stage of a byte, summed per block and written to L.debug[blockIdx*8 + stage].
+#define ZH_STAMP(i)                                                              \
+  do {                                                                           \
+    if (PROF) {                                                                  \
+      uint64_t now_;                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                         \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+      __builtin_amdgcn_sched_barrier(0);                                         \
+      prof[i] += now_ - tprev;                                                   \
+      tprev = now_;                                                              \
+    }                                                                            \
+  } while (0)
+
+template <bool PROF>
+__device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t *__restrict__ fused_g, CmLds &S) {
+  uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t tprev = 0;
   const uint32_t lane = threadIdx.x;
 
   {  // model-independent tables -> LDS
@@ -280,6 +296,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_cm(ZhLaunch L, const 
 
       for (;;) {                                       // one decoded byte per iteration
         // ---- Decoder.decompress prologue (Decoder.cs:36-45)
+        if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
         if (d.curr == 0)
           for (int i = 0; i < 4; ++i) d.curr = d.curr << 8 | (uint32_t)in_get(in, lane);
         int y = dec_step(d, 0, in, lane);              // EOS flag
@@ -289,10 +306,12 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_cm(ZhLaunch L, const 
           if (d.curr != 0) { status = ZH_E_EOS; break; }
           c = -1;
         } else {
+          ZH_STAMP(0);
           // ---- probabilities for every context this byte can reach
           const uint32_t hm = h0 & cm_mask;
           const uint32_t w = hm >> 9, lo9 = hm & 511, g0 = lo9 >> 4, x = lo9 & 15;
           const uint32_t slot = win_get(w, tag, stamp, clock++, S, table, lane);
+          ZH_STAMP(1);
           uint32_t *win = &S.win[slot][0];
           const uint32_t gb = g0 ^ 16;                 // groups of the second nibble: gb ^ n
           const uint32_t ia = (g0 << 4) | (lane & 15);
@@ -307,6 +326,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_cm(ZhLaunch L, const 
 #pragma unroll
           for (int k = 0; k < 4; ++k) pb[k] = S.fused[cmb[k] >> 17];
 
+          ZH_STAMP(2);
           // ---- first nibble
           uint32_t j = 1;
 #pragma unroll
@@ -316,6 +336,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_cm(ZhLaunch L, const 
             j = j * 2 + (uint32_t)y;
           }
           if (y < 0) { status = y; break; }
+          ZH_STAMP(3);
           const uint32_t n1 = j & 15;
           // ---- second nibble: group (gb ^ n1), held by lanes (ga&3)*16.. in register ga>>2
           const uint32_t ga = (gb ^ n1) & 15, kb = ga >> 2, lb = (ga & 3) * 16;
@@ -328,6 +349,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_cm(ZhLaunch L, const 
             j2 = j2 * 2 + (uint32_t)y;
           }
           if (y < 0) { status = y; break; }
+          ZH_STAMP(4);
           const uint32_t n2 = j2 & 15;
           c = (int)(n1 << 4 | n2);
 
@@ -353,6 +375,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_cm(ZhLaunch L, const 
             if (vis2) win[isel] = nv2;
           }
 
+          ZH_STAMP(5);
           // ---- HCOMP (Predictor.cs:464-470): h[0] = H(0) after z.run(c)
           if (hk == 1) h0 = (uint32_t)c << hshift;     // "a<<= K  *d=a  halt"
           else {
@@ -393,6 +416,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_cm(ZhLaunch L, const 
             pp_state = 5;
           }
         }
+        ZH_STAMP(6);
         if (c < 0) break;
       }
 
@@ -409,8 +433,25 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_cm(ZhLaunch L, const 
         L.results[si] = res;
       }
     }
+    if (PROF && lane == 0 && L.debug)
+      for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
     __syncthreads();
   }
+}
+
+extern "C" __global__ __launch_bounds__(64) void zh_decode_cm(ZhLaunch L, const uint16_t *__restrict__ fused_g) {
+  __shared__ CmLds S;
+  decode_cm_body<false>(L, fused_g, S);
+}
+
+extern "C" __global__ __launch_bounds__(64) void zh_decode_cm_prof(ZhLaunch L, const uint16_t *__restrict__ fused_g) {
+  __shared__ CmLds S;
+  decode_cm_body<true>(L, fused_g, S);
+}
+
+extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL(zh_decode_cm_prof, dim3(grid), dim3(64), 0, stream, *L, fused);
+  return hipGetLastError();
 }
 
 extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream) {

@@ -109,4 +109,5 @@ struct ZhLaunch {          // kernel arguments (one struct, passed by value)
   uint32_t pad;
   uint64_t budget;         // ZPAQL instructions per run()
   uint64_t in_total;       // length of the whole stream at `in`
+  uint64_t *debug;         // diagnostic builds only (cycle sums); NULL otherwise
 };
