@@ -108,6 +108,7 @@ typedef struct zpaqhip_seg_result {
   uint32_t pp_state;     /* PostProcessor state at the end (1 PASS, 5 PROG) */
   uint64_t out_off;      /* where the segment's plaintext starts in the output */
   uint64_t out_len;      /* plaintext bytes produced (counted even past capacity) */
+  uint64_t in_used;      /* coded bytes the decoder consumed; != data_len means the stream is damaged */
 } zpaqhip_seg_result;
 
 typedef struct zpaqhip_opts {

@@ -41,3 +41,243 @@ def test_ragged_sizes(ctx, n):
     for model in ("l1", "mid"):
         s = util.block(model, d)
         assert ctx.decompress(s, verify_sha1=True).tobytes() == d
+
+
+# ---------------------------------------------------------------------------------------
+import hashlib
+import json
+import os
+
+from zpaqsharp_amd import models, synth, zpaql
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TAG = bytes([0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3])
+
+
+def _manifest():
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", sorted(_manifest()))
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_golden_fixtures(ctx, name, kernel):
+    e = _manifest()[name]
+    stream = open(os.path.join(GOLD, name + ".zpaq"), "rb").read()
+    got = ctx.decompress(stream, verify_sha1=True, kernel=kernel).tobytes()
+    assert len(got) == e["plain_len"] and hashlib.sha1(got).hexdigest() == e["plain_sha1"]
+
+
+@pytest.mark.parametrize("kind", ["T", "R"])
+def test_generic_and_lane_kernels_agree_with_oracle(ctx, kind):
+    s, _ = synth.stream("l1", kind, nblocks=6, block_size=50000, threads=4)
+    want = oracle.decompress(s.tobytes(), cap=300016)
+    for kernel in (1, 0):
+        got = ctx.decompress(s, verify_sha1=True, kernel=kernel)
+        assert got.tobytes() == want
+        assert ctx.stats().kernel_kind == (1 if kernel == 1 else 2)
+
+
+def test_cm_models_with_other_shapes(ctx):
+    # wider/narrower CM tables, an HCOMP that is not the recognised shift form, and a PCOMP on a CM model
+    cfgs = [
+        "comp 1 0 0 0 1 0 cm 9 3 hcomp a<<= 3 *d=a halt end",
+        "comp 2 2 0 0 1 0 cm 20 255 hcomp *b=a a=0 hash b-- hash *d=a b++ b++ halt end",     # order-2 hash
+        "comp 0 0 0 0 1 0 cm 22 40 hcomp a*= 77 a+= 5 *d=a halt end",
+        "comp 0 0 0 0 1 0 cm 8 255 hcomp a<<= 9 *d=a halt end",                              # < 9 bits: generic kernel
+    ]
+    data = util.text(30000, seed=4)
+    for cfg in cfgs:
+        m = zpaql.assemble(cfg)
+        s = synth.compress_block(m, data)
+        assert oracle.decompress(s) == data
+        assert ctx.decompress(s, verify_sha1=True).tobytes() == data
+    m = zpaql.assemble("comp 0 0 0 3 1 0 cm 17 255 hcomp a<<= 9 *d=a halt " + models.E8E9_PCOMP.strip())
+    x = util.x86ish(20000, seed=5)
+    s = synth.compress_block(m, x)
+    assert oracle.decompress(s) == x
+    assert ctx.decompress(s, verify_sha1=True).tobytes() == x
+
+
+def test_multi_segment_blocks(ctx):
+    for model in ("l1", "mid", "max+e8e9"):
+        m = models.get(model)
+        parts = [util.x86ish(n, n) if "e8e9" in model else util.text(n, n) for n in (3000, 0, 1, 2000)]
+        c = oracle.Compressor(60000)
+        c.write_tag(); c.start_block(m.header)
+        for i, d in enumerate(parts):
+            c.start_segment(b"seg%d" % i, str(len(d)).encode())
+            if i == 0:
+                c.post_process(m.pcomp)
+            c.compress(oracle.e8e9(d) if "e8e9" in model else d)
+            c.end_segment(oracle.sha1(d) if i % 2 == 0 else None)
+        c.end_block()
+        s = c.getvalue()
+        want = oracle.decompress(s)
+        if "e8e9" not in model:
+            assert want == b"".join(parts)
+        assert ctx.decompress(s, verify_sha1="e8e9" not in model).tobytes() == want
+
+
+def test_unmodelled_store_block(ctx):
+    hdr = zpaql.assemble("comp 0 0 0 0 0 hcomp halt end").header
+    payload = b"\0" + bytes(range(256)) * 3
+    chunks = payload[:100], payload[100:]
+    body = b"".join(len(c).to_bytes(4, "big") + c for c in chunks) + b"\0\0\0\0"
+    s = TAG + b"zPQ" + bytes([2, 1]) + hdr + b"\x01name\0comment\0\0" + body + bytes([254, 255])
+    want = oracle.decompress(s)
+    assert want == payload[1:]
+    assert ctx.decompress(s).tobytes() == want
+
+
+def test_no_size_hint_in_comment(ctx):
+    d1, d2 = util.text(7000, 1), util.text(100, 2)
+    s = util.block("l1", d1, comment=b"no size here") + util.block("mid", d2, comment=b"jDC\x01")
+    assert ctx.decompress(s, verify_sha1=True).tobytes() == d1 + d2
+    # a wrong size hint must not corrupt the layout either
+    s = util.block("l1", d1, comment=b"5") + util.block("mid", d2, comment=b"99999")
+    assert ctx.decompress(s, verify_sha1=True).tobytes() == d1 + d2
+
+
+@pytest.mark.parametrize("model", ["l1", "mid"])
+def test_corrupt_streams_report_the_oracle_error(ctx, model):
+    data = util.text(20000, seed=9)
+    good = util.block(model, data)
+    sc = z.scan(good)
+    g = sc.segments[0]
+    rng = np.random.default_rng(1)
+    outcomes = set()
+    for trial in range(24):
+        s = bytearray(good)
+        pos = int(g.data_off + rng.integers(4, g.data_len - 8))
+        s[pos] ^= 1 << int(rng.integers(0, 8))
+        if bytes(s[pos - 3:pos + 4]).count(0) >= 4:
+            continue
+        s = bytes(s)
+        try:
+            want = ("ok", oracle.decompress(s, cap=1 << 20))
+        except oracle.OracleError as e:
+            want = ("err", str(e))
+        try:
+            got = ("ok", ctx.decompress(s).tobytes())
+        except z.ZpaqError as e:
+            got = ("err", str(e))
+        assert got == want, (trial, pos)
+        outcomes.add(want[0] if want[0] == "ok" else want[1])
+    assert len(outcomes) >= 1
+    # SHA-1 verification catches silent corruption
+    s = bytearray(good)
+    s[-10] ^= 0x55                                       # inside the stored checksum
+    with pytest.raises(z.ZpaqError) as e:
+        ctx.decompress(bytes(s), verify_sha1=True)
+    assert e.value.code == -21
+
+
+def test_truncated_coded_data(ctx):
+    good = util.block("mid", util.text(5000))
+    g = z.scan(good).segments[0]
+    cut = good[:g.data_off + g.data_len // 2] + b"\0\0\0\0" + bytes([254, 255])
+    try:
+        want = ("ok", oracle.decompress(cut, cap=1 << 20))
+    except oracle.OracleError as e:
+        want = ("err", str(e))
+    try:
+        got = ("ok", ctx.decompress(cut).tobytes())
+    except z.ZpaqError as e:
+        got = ("err", str(e))
+    assert got == want
+
+
+def test_zpaql_error_and_budget(ctx):
+    data = util.text(100)
+    bad = zpaql.assemble("comp 0 0 0 0 1 0 cm 9 255 hcomp error halt end")
+    s = synth_block_with_header(bad.header, data)
+    with pytest.raises(z.ZpaqError) as e:
+        ctx.decompress(s)
+    assert e.value.code == -4 and "ZPAQL execution error" in str(e.value)
+    with pytest.raises(oracle.OracleError, match="ZPAQL execution error"):
+        oracle.decompress(s)
+    loop = zpaql.assemble("comp 0 0 0 0 1 0 cm 9 255 hcomp do forever halt end")
+    s = synth_block_with_header(loop.header, data)
+    with pytest.raises(z.ZpaqError) as e:
+        ctx.decompress(s, zpaql_budget=100000)
+    assert e.value.code == -26
+
+
+def synth_block_with_header(header, data):
+    """A block whose HCOMP misbehaves cannot be ENCODED; borrow the coded bytes of a well-formed twin."""
+    twin = zpaql.assemble("comp 0 0 0 0 1 0 cm 9 255 hcomp halt end")
+    assert len(twin.header) <= len(header)
+    s = synth.compress_block(twin, data)
+    i = s.index(twin.header)
+    return s[:i] + header + s[i + len(twin.header):]
+
+
+def test_block_table_api_subset_and_count_mode(ctx):
+    import torch
+    s, offs = synth.stream("l1", "T", nblocks=5, block_size=30000, threads=4)
+    sc = z.scan(s)
+    d_in = torch.from_numpy(s).cuda()
+    d_out = torch.zeros(5 * 30000, dtype=torch.uint8, device="cuda")
+    ids = [4, 1]
+    rc, res = ctx.decode_blocks_device(d_in.data_ptr(), s.size, sc, d_out.data_ptr(), [0, 30000], [30000, 30000], ids=ids)
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got[:30000], synth.plain("T", 4, 30000)) and np.array_equal(got[30000:60000], synth.plain("T", 1, 30000))
+    assert res[4].status == 0 and res[4].out_len == 30000 and res[4].out_off == 0 and res[1].out_off == 30000
+    assert res[0].status == 0 and res[0].out_len == 0                        # entries of other blocks are left untouched
+    assert res[4].in_used == sc.segments[4].data_len
+    # count-only mode: capacity 0 -> nothing written, true length reported
+    d_out.zero_()
+    rc, res = ctx.decode_blocks_device(d_in.data_ptr(), s.size, sc, d_out.data_ptr(), [0] * 5, [0] * 5, raise_on_error=False)
+    assert all(r.status == -20 and r.out_len == 30000 for r in res) and int(d_out.sum()) == 0
+    # partial capacity: prefix written, rest counted
+    rc, res = ctx.decode_blocks_device(d_in.data_ptr(), s.size, sc, d_out.data_ptr(), [0], [1000], ids=[2], raise_on_error=False)
+    assert res[2].status == -20 and res[2].out_len == 30000
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got[:1000], synth.plain("T", 2, 30000)[:1000]) and int(got[1000:].sum()) == 0
+
+
+def test_unaligned_output_offsets(ctx):
+    import torch
+    s, _ = synth.stream("l1", "T", nblocks=4, block_size=5003, threads=2)
+    sc = z.scan(s)
+    d_in = torch.from_numpy(s).cuda()
+    d_out = torch.zeros(4 * 5003 + 64, dtype=torch.uint8, device="cuda")
+    off = [1 + i * 5003 for i in range(4)]
+    ctx.decode_blocks_device(d_in.data_ptr(), s.size, sc, d_out.data_ptr(), off, [5003] * 4)
+    got = d_out.cpu().numpy()
+    assert got[0] == 0 and int(got[1 + 4 * 5003:].sum()) == 0
+    for i in range(4):
+        assert np.array_equal(got[off[i]:off[i] + 5003], synth.plain("T", i, 5003))
+
+
+def test_reader_writer_callback_form(ctx):
+    data = util.text(70000, seed=11)
+    s = util.block("l1", data[:40000]) + util.block("min", data[40000:])
+    pos, out = [0], bytearray()
+
+    def rd(n):
+        chunk = s[pos[0]:pos[0] + min(n, 777)]
+        pos[0] += len(chunk)
+        return chunk
+
+    ctx.decompress_cb(rd, out.extend, verify_sha1=True)
+    assert bytes(out) == data
+
+
+def test_full_size_l1_blocks_round_trip(ctx):
+    """BASELINE configs[1] shape at reduced block count: 4 MiB blocks, in-stream SHA-1 + generator plaintext."""
+    nb, bs = 48, 4 << 20
+    s, _ = synth.stream("l1", "T", nblocks=nb, block_size=bs)
+    got = ctx.decompress(s, verify_sha1=True)
+    assert got.size == nb * bs
+    for b in range(nb):
+        assert np.array_equal(got[b * bs:(b + 1) * bs], synth.plain("T", b, bs)), b
+
+
+def test_more_blocks_than_slots(ctx):
+    s, _ = synth.stream("l1", "T", nblocks=40, block_size=3000, threads=4)
+    want = np.concatenate([synth.plain("T", b, 3000) for b in range(40)])
+    for kernel in (0, 1):
+        got = ctx.decompress(s, verify_sha1=True, max_concurrent=7, kernel=kernel)
+        assert np.array_equal(got, want)

@@ -35,7 +35,8 @@ class Segment(C.Structure):
 
 
 class SegResult(C.Structure):
-    _fields_ = [("status", C.c_int32), ("pp_state", C.c_uint32), ("out_off", C.c_uint64), ("out_len", C.c_uint64)]
+    _fields_ = [("status", C.c_int32), ("pp_state", C.c_uint32), ("out_off", C.c_uint64), ("out_len", C.c_uint64),
+                ("in_used", C.c_uint64)]
 
 
 class Opts(C.Structure):
@@ -70,6 +71,12 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the ZPAQ decode path)")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64; importing it first makes
+    # libzpaqhip.so bind to that copy, so tensors and this library share devices and streams.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, errp = C.c_void_p, C.c_size_t, C.POINTER(Err)
     L.zpaqhip_version.restype = C.c_int

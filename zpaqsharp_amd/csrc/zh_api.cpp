@@ -353,6 +353,11 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
       results[si].pp_state = res[si].pp_state;
       results[si].out_off = res[si].out_off;
       results[si].out_len = res[si].out_len;
+      results[si].in_used = res[si].in_used;
+      // A decoder that stopped anywhere but at the scanned end of the coded data means a
+      // damaged stream: the reference would now read its end-of-segment marker from the
+      // wrong place (Decompresser.cs:163-194).
+      if (res[si].status == ZPAQHIP_OK && res[si].in_used != segs[si].data_len) results[si].status = res[si].status = ZPAQHIP_E_SEGEND;
       total_out += res[si].out_len;
       if (res[si].status != ZPAQHIP_OK && res[si].status != ZPAQHIP_E_OUTPUT_FULL && first_bad == ZPAQHIP_OK &&
           res[si].status != ZH_E_SKIPPED) {

@@ -71,8 +71,10 @@ __device__ __forceinline__ uint32_t load_chunk(const InBuf &in, uint64_t chunk, 
   return off < in.total ? *reinterpret_cast<const uint32_t *>(in.stream + off) : 0u;
 }
 
-__device__ __forceinline__ void in_open(InBuf &in, uint64_t off, uint64_t len, uint32_t lane) {
-  in.pos = off; in.end = off + len;
+__device__ __forceinline__ void in_open(InBuf &in, uint64_t off, uint32_t lane) {
+  // Decoder.get() reads the caller's Reader, which does not stop at the segment end
+  // (Decoder.cs:112-122): only the end of the stream is EOF.
+  in.pos = off; in.end = in.total;
   in.chunk = off >> 8;
   in.cur = load_chunk(in, in.chunk, lane);
   in.nxt = load_chunk(in, in.chunk + 1, lane);
@@ -288,11 +290,13 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
         if (lane == 0) {
           ZhSegResult res;
           res.status = ZH_E_SKIPPED; res.pp_state = (uint32_t)pp_state; res.out_off = b_out_off + produced0; res.out_len = 0;
+          res.in_used = 0;
           L.results[si] = res;
         }
         continue;
       }
-      in_open(in, uni64(L.segs[si].in_off), uni64(L.segs[si].in_len), lane);
+      const uint64_t seg_off = uni64(L.segs[si].in_off);
+      in_open(in, seg_off, lane);
 
       for (;;) {                                       // one decoded byte per iteration
         // ---- Decoder.decompress prologue (Decoder.cs:36-45)
@@ -430,6 +434,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
         ZhSegResult res;
         res.status = status; res.pp_state = (uint32_t)pp_state;
         res.out_off = b_out_off + produced0; res.out_len = produced - produced0;
+        res.in_used = in.pos - seg_off;
         L.results[si] = res;
       }
     }

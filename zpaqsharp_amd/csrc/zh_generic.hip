@@ -263,13 +263,15 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_generic(ZhLaunch L) {
         ZhSegResult res;
         res.out_off = bd.out_off + out.len;
         if (failed) {
-          res.status = ZH_E_SKIPPED; res.pp_state = (uint32_t)pp.state; res.out_len = 0;
+          res.status = ZH_E_SKIPPED; res.pp_state = (uint32_t)pp.state; res.out_len = 0; res.in_used = 0;
           L.results[si] = res;
           continue;
         }
         const ZhSegDesc sd = L.segs[si];
         Src in;
-        in.p = L.in + sd.in_off; in.end = in.p + sd.in_len;
+        // Decoder.get() reads the caller's Reader, which does not stop at the segment end
+        // (Decoder.cs:112-122): only the end of the stream is EOF.
+        in.p = L.in + sd.in_off; in.end = L.in + L.in_total;
         const uint64_t start = out.len;
         int status = 0;
         for (;;) {                                     // Decompresser.decompress(-1), Decompresser.cs:121-153
@@ -282,6 +284,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_generic(ZhLaunch L) {
         if (!status && out.len > out.cap) status = ZH_E_OUTPUT_FULL;
         if (status && status != ZH_E_OUTPUT_FULL) failed = 1;
         res.status = status; res.pp_state = (uint32_t)pp.state; res.out_len = out.len - start;
+        res.in_used = (uint64_t)(in.p - (L.in + sd.in_off));
         L.results[si] = res;
       }
     }

@@ -83,6 +83,7 @@ struct ZhSegResult {       // == zpaqhip_seg_result
   int32_t status;
   uint32_t pp_state;
   uint64_t out_off, out_len;
+  uint64_t in_used;        // coded bytes consumed by the decoder
 };
 
 struct ZhTables {          // Predictor.cs:48-79 + StateTable.cs
