@@ -167,6 +167,17 @@ int zpaqhip_decompress(zpaqhip_ctx *ctx, const uint8_t *in, size_t in_len,
                        uint8_t *out, size_t out_cap, size_t *out_len,
                        const zpaqhip_opts *opts, zpaqhip_err *err);
 
+/* ---- same, but per-segment outcomes are handed back instead of aborting at the first bad
+ * block: this is what a step-wise Decompresser mirror (findBlock / findFilename /
+ * decompress(n) / readSegmentEnd, Decompresser.cs:29-194) needs to raise an error only when
+ * the caller reaches the failing segment, as the reference does.  results[i] describes
+ * segment i of zpaqhip_scan's table (out_off relative to `out`).  Returns
+ * ZPAQHIP_E_ARG with *n_results = required count if result_cap is too small. */
+int zpaqhip_decompress_segments(zpaqhip_ctx *ctx, const uint8_t *in, size_t in_len,
+                                uint8_t *out, size_t out_cap, size_t *out_len,
+                                zpaqhip_seg_result *results, size_t result_cap, size_t *n_results,
+                                const zpaqhip_opts *opts, zpaqhip_err *err);
+
 /* ---- same, streaming through Reader/Writer-shaped callbacks -------------- */
 int zpaqhip_decompress_cb(zpaqhip_ctx *ctx, zpaqhip_read_fn read_fn, zpaqhip_write_fn write_fn,
                           void *user, const zpaqhip_opts *opts, zpaqhip_err *err);

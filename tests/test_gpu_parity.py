@@ -281,3 +281,111 @@ def test_more_blocks_than_slots(ctx):
     for kernel in (0, 1):
         got = ctx.decompress(s, verify_sha1=True, max_concurrent=7, kernel=kernel)
         assert np.array_equal(got, want)
+
+
+def test_python_mirror_of_the_reference_api(ctx):
+    from zpaqsharp_amd import decompresser as D
+    a, b, c = util.text(5000, 1), util.text(0, 2), util.x86ish(3000, 3)
+    s = util.block("l1", a, filename=b"a.txt") + util.block("mid", b) + util.block("max+e8e9", c, filename=b"c.bin")
+    # LibZPAQ.decompress(Reader, Writer)
+    w = D.BytesWriter()
+    D.decompress(D.BytesReader(s), w, context=ctx)
+    assert bytes(w.buf) == a + b + c == oracle.decompress(s)
+    # documented step-wise order, decompress(n) resumption, sha1 string, hcomp()
+    d, od = D.Decompresser(ctx), oracle.Decompresser(s)
+    d.setInput(D.BytesReader(s))
+    names, total = [], bytearray()
+    while d.findBlock():
+        assert d.memory() == od.find_block()
+        h = D.BytesWriter(); d.hcomp(h)
+        assert bytes(h.buf) == od.hcomp()
+        while True:
+            fn = D.BytesWriter()
+            more = d.findFilename(fn)
+            ofn = od.find_filename()
+            assert more == (ofn is not None)
+            if not more:
+                break
+            assert bytes(fn.buf) == ofn
+            cm = D.BytesWriter(); d.readComment(cm)
+            assert bytes(cm.buf) == od.read_comment()
+            out = D.BytesWriter(); d.setOutput(out)
+            sha = hashlib.sha1(); d.setSHA1(sha)
+            calls = 0
+            while d.decompress(1000):
+                calls += 1
+            want, _ = od.decompress()
+            assert bytes(out.buf) == want and calls == len(want) // 1000
+            stored = d.readSegmentEnd()
+            assert stored == od.read_segment_end() == sha.digest()
+            names.append(bytes(fn.buf)); total += out.buf
+    assert od.find_block() is None and names == [b"a.txt", b"", b"c.bin"] and bytes(total) == a + b + c
+
+
+def test_python_mirror_raises_at_the_failing_segment(ctx):
+    from zpaqsharp_amd import decompresser as D
+    good1, bad, good2 = util.block("l1", util.text(3000, 1)), bytearray(util.block("l1", util.text(3000, 2))), util.block("l1", util.text(500, 3))
+    g = z.scan(bytes(bad)).segments[0]
+    bad[g.data_off + 50] ^= 0x10
+    s = good1 + bytes(bad) + good2
+    d = D.Decompresser(ctx)
+    d.setInput(D.BytesReader(s))
+    out = D.BytesWriter(); d.setOutput(out)
+    assert d.findBlock() and d.findFilename()
+    d.readComment(); assert d.decompress() is False; d.readSegmentEnd()
+    assert bytes(out.buf) == util.text(3000, 1) and not d.findFilename()
+    assert d.findBlock() and d.findFilename()
+    d.readComment()
+    with pytest.raises(z.ZpaqError):
+        d.decompress()
+
+
+_CPP_TEST = r'''
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include "Decompresser.hpp"
+struct In : zpaq::Reader { FILE *f; int get() override { return getc(f); } };
+struct Out : zpaq::Writer { std::string s; void put(int c) override { s.push_back((char)c); } };
+int main(int argc, char **argv) {
+  In in; in.f = fopen(argv[1], "rb");
+  Out out;
+  try { zpaq::decompress(&in, &out); }                       // LibZPAQ.decompress(Reader, Writer)
+  catch (const zpaq::Error &e) { printf("ERR %d %s\n", e.code, e.what()); return 3; }
+  fwrite(out.s.data(), 1, out.s.size(), fopen(argv[2], "wb"));
+  // step-wise with decompress(n) and sha1string
+  rewind(in.f);
+  zpaq::Decompresser d;
+  d.setInput(&in);
+  Out o2; d.setOutput(&o2);
+  int segs = 0, with_sha = 0;
+  while (d.findBlock()) {
+    Out name;
+    while (d.findFilename(&name)) {
+      d.readComment();
+      while (d.decompress(777)) {}
+      char sha[21]; d.readSegmentEnd(sha);
+      ++segs; with_sha += sha[0];
+    }
+  }
+  printf("OK %zu %d %d %d\n", out.s.size(), o2.s == out.s, segs, with_sha);
+  return 0;
+}
+'''
+
+
+def test_cpp_mirror_of_the_reference_api(ctx, tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a, b = util.text(40000, 1), util.x86ish(9000, 2)
+    s = util.block("l1", a) + util.block("max+e8e9", b)
+    (tmp_path / "in.zpaq").write_bytes(s)
+    (tmp_path / "t.cpp").write_text(_CPP_TEST)
+    exe = tmp_path / "t"
+    lib = os.path.join(root, "zpaqsharp_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), "-I", os.path.join(lib, "host"),
+                           str(tmp_path / "t.cpp"), "-o", str(exe), "-L", lib, "-lzpaqhip", f"-Wl,-rpath,{lib}",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe), str(tmp_path / "in.zpaq"), str(tmp_path / "out.bin")]).decode()
+    assert out.split() == ["OK", str(len(a) + len(b)), "1", "2", "2"], out
+    assert (tmp_path / "out.bin").read_bytes() == a + b

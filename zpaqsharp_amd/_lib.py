@@ -57,7 +57,7 @@ WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_int)
 # Every symbol include/zpaqhip.h declares; tests check the library exports them all.
 SYMBOLS = ("zpaqhip_version", "zpaqhip_strerror", "zpaqhip_device_count", "zpaqhip_ctx_create",
            "zpaqhip_ctx_destroy", "zpaqhip_last_stats", "zpaqhip_scan", "zpaqhip_decompress",
-           "zpaqhip_decompress_cb", "zpaqhip_decode_blocks_device", "zpaqhip_read_device_tables")
+           "zpaqhip_decompress_segments", "zpaqhip_decompress_cb", "zpaqhip_decode_blocks_device", "zpaqhip_read_device_tables")
 
 _lib = None
 
@@ -89,6 +89,8 @@ def load():
     L.zpaqhip_last_stats.argtypes = [vp, C.POINTER(Stats)]
     L.zpaqhip_scan.argtypes = [vp, sz, C.POINTER(Block), sz, C.POINTER(sz), C.POINTER(Segment), sz, C.POINTER(sz), errp]
     L.zpaqhip_decompress.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(Opts), errp]
+    L.zpaqhip_decompress_segments.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(SegResult), sz, C.POINTER(sz),
+                                              C.POINTER(Opts), errp]
     L.zpaqhip_decompress_cb.argtypes = [vp, READ_FN, WRITE_FN, vp, C.POINTER(Opts), errp]
     L.zpaqhip_decode_blocks_device.argtypes = [vp, vp, vp, sz, C.POINTER(Block), sz, C.POINTER(Segment), sz,
                                                C.POINTER(C.c_uint32), sz, vp, C.POINTER(C.c_uint64),

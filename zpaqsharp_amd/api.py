@@ -149,6 +149,28 @@ class Context:
             _raise(err, rc)
         return out[:n.value]
 
+    def decompress_segments(self, stream, **opt):
+        """Whole stream, but per-segment outcomes are returned instead of raised:
+        (plaintext ndarray, SegResult array indexed like scan(stream).segments)."""
+        a = _as_u8(stream)
+        o = make_opts(**opt)
+        err, n, nr = Err(), C.c_size_t(0), C.c_size_t(0)
+        res = (SegResult * 1)()
+        out = np.empty(1, np.uint8)
+        cap, rcap = 0, 0
+        for _ in range(3):
+            rc = self._L.zpaqhip_decompress_segments(self._h, a.ctypes.data, a.size, out.ctypes.data, cap, C.byref(n),
+                                                     res, rcap, C.byref(nr), C.byref(o), C.byref(err))
+            if rc in (-20, -25) and (n.value > cap or nr.value > rcap):   # learn sizes, then retry
+                cap, rcap = max(cap, n.value), max(rcap, nr.value)
+                out = np.empty(max(1, cap), np.uint8)
+                res = (SegResult * max(1, rcap))()
+                continue
+            break
+        if rc:
+            _raise(err, rc)
+        return out[:n.value], res
+
     def decompress_cb(self, read_fn, write_fn, **opt) -> None:
         """Streaming form: read_fn(n)->bytes ('' at EOF), write_fn(bytes)."""
         o = make_opts(**opt)

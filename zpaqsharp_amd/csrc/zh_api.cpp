@@ -386,8 +386,14 @@ namespace {
 
 // Decodes a host-resident stream; the plaintext ends up in ctx->out (device),
 // laid out in stream order.  Returns total plaintext length in *total.
+bool data_error(int rc) {                 // per-segment outcomes, as opposed to failures of the call itself
+  return rc < 0 && rc != ZPAQHIP_E_HIP && rc != ZPAQHIP_E_ARG && rc != ZPAQHIP_E_DEVICE_MEM && rc != ZPAQHIP_E_NO_DEVICE &&
+         rc != ZPAQHIP_E_HEADER && rc != ZPAQHIP_E_COMPONENT && rc != ZPAQHIP_E_HM_TOO_BIG;
+}
+
 int decode_stream_to_device(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, const zpaqhip_opts &opts, ScanOut &so,
-                            std::vector<zpaqhip_seg_result> &res, uint64_t *total, zpaqhip_err *err) {
+                            std::vector<zpaqhip_seg_result> &res, uint64_t *total, zpaqhip_err *err,
+                            bool tolerate = false) {
   int rc = scan_stream(in, in_len, so, err);
   if (rc) return rc;
   *total = 0;
@@ -418,7 +424,7 @@ int decode_stream_to_device(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, co
   rc = zpaqhip_decode_blocks_device(c, c->in.p, in, in_len, so.blocks.data(), nb, so.segs.data(), so.segs.size(), nullptr, 0,
                                     c->out.p, off.data(), cap.data(), res.data(), &opts, c->stream, err);
   zpaqhip_stats st1 = c->stats;
-  if (rc) return rc;
+  if (rc && !(tolerate && data_error(rc))) return rc;
   // did every block land exactly where the final layout wants it?
   std::vector<uint64_t> real(nb, 0);
   bool ok = exact_possible;
@@ -438,7 +444,7 @@ int decode_stream_to_device(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, co
                                       0, c->out.p, off.data(), cap.data(), res.data(), &opts, c->stream, err);
     c->stats.kernel_ms += st1.kernel_ms;
     c->stats.launches += st1.launches;
-    if (rc) return rc;
+    if (rc && !(tolerate && data_error(rc))) return rc;
   }
   c->stats.h2d_ms = h2d;
   return ZPAQHIP_OK;
@@ -490,6 +496,37 @@ int zpaqhip_decompress(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint8_t
     c->stats.d2h_ms = ms;
   }
   if (opts.verify_sha1) return verify_sha1(so, res, out, err);
+  return ZPAQHIP_OK;
+}
+
+int zpaqhip_decompress_segments(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                                size_t *out_len, zpaqhip_seg_result *results, size_t result_cap, size_t *n_results,
+                                const zpaqhip_opts *opts_in, zpaqhip_err *err) {
+  if (!c || (!in && in_len) || !out_len || !n_results || (!out && out_cap) || (!results && result_cap)) {
+    set_err(err, ZPAQHIP_E_ARG, -1, -1);
+    return ZPAQHIP_E_ARG;
+  }
+  const zpaqhip_opts opts = resolve_opts(opts_in);
+  ScanOut so;
+  std::vector<zpaqhip_seg_result> res;
+  uint64_t total = 0;
+  *out_len = 0; *n_results = 0;
+  int rc = decode_stream_to_device(c, in, in_len, opts, so, res, &total, err, true);
+  if (rc) return rc;
+  *out_len = (size_t)total;
+  *n_results = res.size();
+  if (res.size() > result_cap) { set_err(err, ZPAQHIP_E_ARG, -1, -1, "result table too small"); return ZPAQHIP_E_ARG; }
+  if (!res.empty()) memcpy(results, res.data(), res.size() * sizeof(zpaqhip_seg_result));
+  if (total > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, -1, -1); return ZPAQHIP_E_OUTPUT_FULL; }
+  if (total) HIPCHK(hipMemcpy(out, c->out.p, total, hipMemcpyDeviceToHost));
+  if (opts.verify_sha1) {                   // mismatches become per-segment statuses
+    for (size_t s = 0; s < res.size(); ++s) {
+      if (!(so.segs[s].flags & 1) || res[s].status != ZPAQHIP_OK) continue;
+      uint8_t d[20];
+      sha1(out + res[s].out_off, res[s].out_len, d);
+      if (memcmp(d, so.segs[s].sha1, 20)) results[s].status = ZPAQHIP_E_SHA1;
+    }
+  }
   return ZPAQHIP_OK;
 }
 
