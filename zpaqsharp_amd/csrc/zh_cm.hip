@@ -6,21 +6,26 @@
 //  * The CM table slice a byte can touch is one 2 KiB "window": the context
 //    index is h[0] ^ hmap4 with hmap4 < 512 (Predictor.cs:263-266, :463-474), so
 //    all 8 bit-contexts of a byte lie in the 512 entries around h[0].  Windows
-//    are cached in LDS (44 x 2 KiB, fully associative, tags held one per lane
-//    and matched with a single ballot; LRU by per-lane stamps).  For text-like
-//    data every context window lives in LDS for the whole block, so HBM sees only
-//    the stream and the plaintext.  Evicted windows are written back / reloaded
-//    with coalesced 16-byte accesses.
+//    are cached in LDS (44 x 2 KiB, fully associative: one tag per lane, lookup =
+//    one v_cmp + s_ff1; FIFO replacement).  For text-like data every context
+//    window stays in LDS for the whole block, so HBM sees only the stream and the
+//    plaintext.  Victims are written back / windows loaded with coalesced 16-byte
+//    accesses.
 //  * Within a byte each bit position uses a DIFFERENT table entry, so all the
 //    probabilities a byte can need (15 for the first nibble, 240 for the second)
 //    are looked up at once by the 64 lanes (squash(stretch(cm>>17)) fused into
-//    one 64 KiB LDS table) and the bit-serial arithmetic decoder then picks them
-//    with v_readlane: its loop is pure scalar-unit code (Decoder.cs:136-158).
-//  * The 8 entries a byte visited are trained in parallel afterwards
+//    one 64 KiB LDS table); lane j of a 16-lane group holds the entry of nibble
+//    context j, so the bit-serial decoder selects with v_readlane(j).
+//  * The arithmetic decoder (Decoder.decode, Decoder.cs:136-158) is a hand-
+//    scheduled 14-instruction scalar sequence per bit.  A lone wave on a CU pays
+//    ~4 cycles per instruction and ~20 per taken branch (tools/ubench), so the hot
+//    path is straight-line: errors and renormalisation are flags tested with
+//    not-taken branches, and (range*p)>>16 is one s_mul_hi_u32 against p<<16.
+//  * The 8 entries a byte visited are trained by 8 lanes at once afterwards
 //    (Predictor.train, Predictor.cs:486-493 / :1031-1036).
-//  * Compressed bytes arrive through a 256-byte register buffer (one dword per
-//    lane, next chunk prefetched); plaintext leaves through an LDS stage that is
-//    flushed with 16-byte coalesced stores.
+//  * Compressed bytes come from a 256-byte register buffer (one aligned dword per
+//    lane); plaintext is packed into dwords on the scalar unit, parked in a VGPR
+//    with v_writelane and leaves as one coalesced 256-byte store per 256 bytes.
 //
 // Anything this kernel does not specialise (PCOMP programs, unusual HCOMP) runs
 // through the same scalar core as the generic kernel, still on the GPU.
@@ -36,17 +41,20 @@ namespace {
 
 constexpr int kWin = 44;                  // LDS-resident CM windows
 constexpr uint32_t kNoWin = 0xFFFFFFFFu;
-constexpr int kStage = 2048;              // plaintext staging bytes
 
 struct alignas(16) CmLds {
-  uint16_t fused[32768];                  // (squash(stretch(x)) * 2 + 1), x = cm >> 17
+  uint16_t fused[32768];                  // squash(stretch(x)) * 2 + 1, x = cm >> 17
   int32_t dt[1024];
   uint32_t win[kWin][512];
-  uint8_t stage[kStage];
   uint32_t r[256];                        // HCOMP R (generic HCOMP fallback)
   uint32_t pr[256];                       // PCOMP R
+  Vm hz, pz;                              // cold machine state lives here, not in registers
+  Sink sink;                              // output of a PCOMP program (lane 0 only)
 };
 static_assert(sizeof(CmLds) <= 163840, "LDS budget");
+
+#define LIKELY(x) __builtin_expect(!!(x), 1)
+#define UNLIKELY(x) __builtin_expect(!!(x), 0)
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) {
@@ -55,138 +63,173 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane);
 }
+// park[lane] = val with both operands scalar: the lane select has to go through M0 (one
+// constant-bus operand per VALU instruction on gfx9); M0 is saved and restored.
+__device__ __forceinline__ uint32_t wrlane(uint32_t val, uint32_t lane, uint32_t park) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+               : "+v"(park), "=&s"(keep) : "s"(uni(val)), "s"(uni(lane)));
+  return park;
+}
 
-// Compressed-byte reader: 256-byte aligned chunks of the stream, one dword per lane.
+// NOTE on 64-bit values in this file: the scalar unit has no ordered 64-bit compare, so any
+// `a < b` on uint64_t is selected onto the vector unit and turns a uniform branch into an
+// exec-mask dance.  The per-byte paths therefore only ever compare 32-bit counters.
+
+// ---- compressed-byte reader: one 256-byte chunk of the stream, a dword per lane ----
 struct InBuf {
   const uint8_t *stream;                  // whole stream (uniform)
-  uint64_t total;                         // stream length
-  uint64_t pos, end;                      // absolute byte cursor / end of this segment
-  uint32_t cur, nxt;                      // per-lane dwords of chunk(pos) and the next chunk
-  uint64_t chunk;                         // index of the chunk held in `cur`
+  uint64_t total;                         // stream length = EOF (Decoder.get reads the caller's Reader,
+                                          // which does not stop at a segment end: Decoder.cs:112-122)
+  uint64_t cbase;                         // stream offset of the chunk in `cur` (multiple of 4)
+  uint32_t k;                             // cursor inside the chunk: position = cbase + k
+  uint32_t avail;                         // valid bytes in the chunk (<= 256)
+  uint32_t cur;                           // per-lane dword of the chunk
 };
 
-__device__ __forceinline__ uint32_t load_chunk(const InBuf &in, uint64_t chunk, uint32_t lane) {
-  uint64_t off = (chunk << 8) + 4ull * lane;
-  // whole-dword reads; the stream buffer is readable up to its 4-byte rounded end
-  return off < in.total ? *reinterpret_cast<const uint32_t *>(in.stream + off) : 0u;
+__device__ __forceinline__ uint64_t in_pos(const InBuf &in) { return in.cbase + in.k; }
+
+__device__ __forceinline__ void in_seek(InBuf &in, uint64_t pos, uint32_t lane) {
+  in.cbase = pos & ~3ull;
+  in.k = (uint32_t)(pos & 3);
+  const uint64_t left = in.total > in.cbase ? in.total - in.cbase : 0;
+  in.avail = left < 256 ? (uint32_t)left : 256u;
+  const uint32_t o = 4u * lane;           // whole-dword reads; the stream buffer is readable up to its 4-byte rounded end
+  in.cur = o < in.avail ? *reinterpret_cast<const uint32_t *>(in.stream + in.cbase + o) : 0u;
 }
 
-__device__ __forceinline__ void in_open(InBuf &in, uint64_t off, uint32_t lane) {
-  // Decoder.get() reads the caller's Reader, which does not stop at the segment end
-  // (Decoder.cs:112-122): only the end of the stream is EOF.
-  in.pos = off; in.end = in.total;
-  in.chunk = off >> 8;
-  in.cur = load_chunk(in, in.chunk, lane);
-  in.nxt = load_chunk(in, in.chunk + 1, lane);
-}
-
-// Decoder.get() (Decoder.cs:112-122): next coded byte, or -1 past the segment.
+// Decoder.get(): next coded byte, or -1 at the end of the stream.
 __device__ __forceinline__ int in_get(InBuf &in, uint32_t lane) {
-  if (in.pos >= in.end) return -1;
-  uint64_t ch = in.pos >> 8;
-  if (ch != in.chunk) {                   // crossed into the prefetched chunk
-    in.cur = in.nxt;
-    in.chunk = ch;
-    in.nxt = load_chunk(in, ch + 1, lane);
+  if (UNLIKELY(in.k >= in.avail)) {
+    in_seek(in, in_pos(in), lane);
+    if (in.k >= in.avail) return -1;
   }
-  uint32_t k = (uint32_t)in.pos & 255;
-  ++in.pos;
+  const uint32_t k = in.k++;
   return (int)((rdlane(in.cur, k >> 2) >> ((k & 3) * 8)) & 255);
 }
 
-// Plaintext writer: bytes collect in LDS and leave in 16-byte coalesced stores.
+// ---- plaintext writer: dwords assembled on the SALU, parked in a VGPR, 256-byte stores ----
 struct OutBuf {
   uint8_t *base;                          // block's output base (uniform)
-  uint64_t cap, len;                      // capacity / bytes produced
-  uint64_t flushed;                       // bytes already in HBM
+  uint64_t cap, len;                      // capacity / bytes produced (len counts past cap)
+  uint64_t stored;                        // bytes already in HBM
+  uint32_t room;                          // bytes that may still be stored (clamped to 32 bits, refreshed per chunk)
+  uint32_t word;                          // bytes of the current dword (scalar)
+  uint32_t park;                          // per-lane: dword (vpos>>2)&63 of the current 256-byte chunk
 };
 
-__device__ void out_flush(OutBuf &o, CmLds &S, uint32_t lane, bool final) {
-  // stage[] holds bytes [flushed, min(len,cap)); LDS index = absolute address & (kStage-1),
-  // so 16-byte groups of LDS line up with 16-byte groups of the destination.
-  const uint64_t lim = o.len < o.cap ? o.len : o.cap;
-  const uintptr_t base = (uintptr_t)o.base;
-  const uintptr_t a0 = base + o.flushed, a1 = base + lim;
-  if (a0 >= a1) return;
-  uintptr_t v0 = (a0 + 15) & ~(uintptr_t)15;           // end of the unaligned head
-  if (v0 > a1) v0 = a1;
-  uintptr_t v1 = a1 & ~(uintptr_t)15;                  // end of the 16-byte groups
-  if (v1 < v0) v1 = v0;
-  for (uintptr_t a = a0 + lane; a < v0; a += 64) *(uint8_t *)a = S.stage[a & (kStage - 1)];
-  for (uintptr_t a = v0 + 16ull * lane; a < v1; a += 16 * 64)
-    *reinterpret_cast<uint4 *>(a) = *reinterpret_cast<const uint4 *>(&S.stage[a & (kStage - 1)]);
-  if (final) {
-    for (uintptr_t a = v1 + lane; a < a1; a += 64) *(uint8_t *)a = S.stage[a & (kStage - 1)];
-    v1 = a1;
-  }
-  o.flushed = v1 - base;
+__device__ __forceinline__ void out_room(OutBuf &o) {
+  const uint64_t r = o.cap > o.len ? o.cap - o.len : 0;
+  o.room = r > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)r;
 }
 
-__device__ __forceinline__ void out_put(OutBuf &o, CmLds &S, uint32_t c, uint32_t lane) {
-  if (o.len < o.cap) {
-    uintptr_t a = (uintptr_t)o.base + o.len;
-    if (lane == 0) S.stage[a & (kStage - 1)] = (uint8_t)c;
-    ++o.len;
-    if (o.len - o.flushed >= kStage - 32) out_flush(o, S, lane, false);
-  } else ++o.len;
+// Writes bytes [stored, lim) out of the parked chunk.  vpos = (base & 255) + position, so the
+// chunk in `park` is 256-byte aligned in memory and lane l holds its bytes 4l..4l+3.
+__device__ __forceinline__ void out_flush(OutBuf &o, uint32_t lane) {
+  const uint64_t lim = o.len < o.cap ? o.len : o.cap;
+  if (lim > o.stored) {
+    const uint32_t phase = (uint32_t)((uintptr_t)o.base & 255);
+    const uint64_t vend = phase + lim;
+    uint32_t park = o.park;
+    if (vend & 3) park = wrlane(o.word, (uint32_t)((vend >> 2) & 63), park);
+    const uint64_t v0 = phase + o.stored, v1 = vend;                 // virtual byte range to write
+    const uint64_t chunk_v = (v1 - 1) & ~255ull;                     // the parked chunk (holds the last byte)
+    const uint64_t lv = chunk_v + 4ull * lane;                       // this lane's dword, virtual
+    uint8_t *dst = o.base + (lv - phase);
+    if (lv >= v0 && lv + 4 <= v1) *reinterpret_cast<uint32_t *>(dst) = park;
+    else
+      for (int i = 0; i < 4; ++i)
+        if (lv + i >= v0 && lv + i < v1) dst[i] = (uint8_t)(park >> (8 * i));
+    o.stored = lim;
+  }
+  out_room(o);
+}
+
+__device__ __forceinline__ void out_put(OutBuf &o, uint32_t c, uint32_t lane) {
+  const uint32_t v = (uint32_t)(uintptr_t)o.base + (uint32_t)o.len;  // low bits of the virtual position
+  ++o.len;
+  if (UNLIKELY(o.room == 0)) return;                                 // count-only past the capacity
+  --o.room;
+  const uint32_t sh = (v & 3) * 8;
+  o.word = sh ? (o.word | c << sh) : c;
+  if ((v & 3) == 3) {
+    o.park = wrlane(o.word, (v >> 2) & 63, o.park);
+    if (UNLIKELY((v & 255) == 255)) out_flush(o, lane);
+  }
 }
 
 struct Dec { uint32_t low, high, curr; };
 
-// Decoder.decode (Decoder.cs:136-158) on the scalar unit.  p16 = predict()*2+1 or 0.
-// Returns the bit, or a negative status.
-__device__ __forceinline__ int dec_step(Dec &d, uint32_t p16, InBuf &in, uint32_t lane) {
-  uint32_t range = d.high - d.low;
-  uint32_t t = d.curr - d.low;
-  if (t > range) return ZH_E_CORRUPT;     // curr < low || curr > high
-  uint32_t off = (uint32_t)(((uint64_t)range * p16) >> 16);
-  int y = t <= off;
-  if (y) d.high = d.low + off;
-  else d.low = d.low + off + 1;
-  while ((d.high ^ d.low) < 0x1000000u) {
-    d.high = d.high << 8 | 255;
-    d.low = d.low << 8;
-    d.low += (d.low == 0);
+// One Decoder.decode step (Decoder.cs:136-158) on the scalar unit.
+//   ps  = p16 << 16 where p16 = predict()*2+1 (or 0 for the EOS flag): (range*p16)>>16 == mulhi(range, ps)
+//   j   = (j << 1) | y
+//   bad |= (curr < low || curr > high)            ("archive corrupted")
+//   rn  = (high ^ low) < 2^24  after the split    (renormalisation needed)
+#define ZH_DEC_STEP(d, ps, j, bad, rn)                                                              \
+  do {                                                                                              \
+    uint32_t r_, t_, off_, mid_, m1_, x_;                                                           \
+    asm volatile(                                                                                   \
+        "s_sub_u32 %[r], %[high], %[low]\n\t"                                                       \
+        "s_sub_u32 %[t], %[curr], %[low]\n\t"                                                       \
+        "s_mul_hi_u32 %[off], %[r], %[p]\n\t"                                                       \
+        "s_cmp_gt_u32 %[t], %[r]\n\t"                                                               \
+        "s_cselect_b32 %[bd], 1, %[bd]\n\t"                                                         \
+        "s_add_u32 %[mid], %[low], %[off]\n\t"                                                      \
+        "s_add_u32 %[m1], %[mid], 1\n\t"                                                            \
+        "s_cmp_le_u32 %[t], %[off]\n\t"                                                             \
+        "s_cselect_b32 %[high], %[mid], %[high]\n\t"                                                \
+        "s_cselect_b32 %[low], %[low], %[m1]\n\t"                                                   \
+        "s_addc_u32 %[jj], %[jj], %[jj]\n\t"                                                        \
+        "s_xor_b32 %[x], %[high], %[low]\n\t"                                                       \
+        "s_cmp_lt_u32 %[x], 0x1000000\n\t"                                                          \
+        "s_cselect_b32 %[rn_], 1, 0"                                                                \
+        : [low] "+s"(d.low), [high] "+s"(d.high), [curr] "+s"(d.curr), [jj] "+s"(j), [bd] "+s"(bad), \
+          [rn_] "=s"(rn),                                                                           \
+          [r] "=&s"(r_), [t] "=&s"(t_), [off] "=&s"(off_), [mid] "=&s"(mid_), [m1] "=&s"(m1_),      \
+          [x] "=&s"(x_)                                                                             \
+        : [p] "s"(ps)                                                                               \
+        : "scc");                                                                                   \
+  } while (0)
+
+// Renormalisation loop of Decoder.decode (Decoder.cs:148-156).  Returns 0 or ZH_E_EOF.
+__device__ __forceinline__ int dec_renorm(Dec &d, InBuf &in, uint32_t lane) {
+  int rc = 0;
+  uint32_t low = d.low, high = d.high, curr = d.curr;
+  do {
+    high = high << 8 | 255;
+    low = low << 8;
+    low = low ? low : 1u;                 // low += (low == 0)
     int c = in_get(in, lane);
-    if (c < 0) return ZH_E_EOF;
-    d.curr = d.curr << 8 | (uint32_t)c;
-  }
-  return y;
+    if (c < 0) { rc = ZH_E_EOF; break; }
+    curr = curr << 8 | (uint32_t)c;
+  } while ((high ^ low) < 0x1000000u);
+  // this rare path may be selected onto the vector unit; hand the state back as scalars
+  d.low = uni(low); d.high = uni(high); d.curr = uni(curr);
+  return (int)uni((uint32_t)rc);
 }
 
-// Window cache: returns the LDS slot holding window w, loading it on a miss.
-__device__ uint32_t win_get(uint32_t w, uint32_t &tag, uint32_t &stamp, uint32_t clock, CmLds &S, uint32_t *table,
-                            uint32_t lane) {
-  uint64_t hit = __ballot(tag == w);
-  uint32_t slot;
-  if (hit) slot = (uint32_t)__ffsll((long long)hit) - 1;
-  else {
-    uint32_t key = lane < (uint32_t)kWin ? stamp : 0xFFFFFFFFu;
-    uint32_t m = key;
-    for (int o = 32; o; o >>= 1) { uint32_t x = (uint32_t)__shfl_xor((int)m, o); m = x < m ? x : m; }
-    uint64_t vm = __ballot(key == m && lane < (uint32_t)kWin);
-    slot = (uint32_t)__ffsll((long long)vm) - 1;
-    uint32_t old = rdlane(tag, slot);
-    uint4 *l = reinterpret_cast<uint4 *>(&S.win[slot][0]);
-    if (old != kNoWin) {                   // write the victim back (coalesced, 2 x 1 KiB)
-      uint4 *g = reinterpret_cast<uint4 *>(table + (uint64_t)old * 512);
-      g[lane] = l[lane];
-      g[lane + 64] = l[lane + 64];
-    }
-    const uint4 *gn = reinterpret_cast<const uint4 *>(table + (uint64_t)w * 512);
-    uint4 a = gn[lane], b = gn[lane + 64];
-    l[lane] = a;
-    l[lane + 64] = b;
-    if (lane == slot) tag = w;
+// Window cache miss: pick the next FIFO victim, write it back, load window w.
+__device__ __forceinline__ uint32_t win_miss(uint32_t w, uint32_t &tag, uint32_t &fifo, CmLds &S, uint32_t *table,
+                                          uint32_t lane) {
+  const uint32_t slot = fifo;
+  fifo = fifo + 1 == (uint32_t)kWin ? 0 : fifo + 1;
+  const uint32_t old = rdlane(tag, slot);
+  uint4 *l = reinterpret_cast<uint4 *>(&S.win[slot][0]);
+  if (old != kNoWin) {                    // write the victim back (coalesced, 2 x 1 KiB)
+    uint4 *g = reinterpret_cast<uint4 *>(table + (uint64_t)old * 512);
+    g[lane] = l[lane];
+    g[lane + 64] = l[lane + 64];
   }
-  if (lane == slot) stamp = clock;
+  const uint4 *gn = reinterpret_cast<const uint4 *>(table + (uint64_t)w * 512);
+  uint4 a = gn[lane], b = gn[lane + 64];
+  l[lane] = a;
+  l[lane + 64] = b;
+  if (lane == slot) tag = w;
   return slot;
 }
 
-}  // namespace
-
 // In-kernel stamps (diagnostic build only: zh_decode_cm_prof): cycles spent per
-// stage of a byte, summed per block and written to L.debug[blockIdx*8 + stage].
+// stage of a byte, summed per block and added to L.debug[stage].
 #define ZH_STAMP(i)                                                              \
   do {                                                                           \
     if (PROF) {                                                                  \
@@ -214,6 +257,12 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
     for (uint32_t i = lane; i < sizeof(S.dt) / 16; i += 64) d2[i] = s2[i];
   }
   __syncthreads();
+
+  // per-lane constants of the lane <-> table-entry mapping
+  const uint32_t l15 = lane & 15;                      // nibble context j held by this lane
+  const uint32_t lgrp = lane >> 4;                     // 16-lane group
+  const uint32_t ltt = 31 - __clz((int)(l15 | 1));     // depth of context j in the nibble tree (0..3)
+  const uint32_t lsh_vis = 4 - ltt, lsh_y = 3 - ltt;
 
   uint8_t *slot_mem = L.arena + (uint64_t)blockIdx.x * L.arena_stride;
 
@@ -248,10 +297,10 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
     }
     __syncthreads();
 
-    uint32_t tag = kNoWin, stamp = 0;                  // per-lane window cache directory
-    uint32_t clock = 1;
+    uint32_t tag = kNoWin;                             // per-lane window directory (lanes >= kWin never match)
+    uint32_t fifo = 0;
 
-    Vm hz;                                             // HCOMP machine (generic form)
+    Vm &hz = S.hz;                                     // HCOMP machine (generic form)
     hz.a = hz.b = hz.c = hz.d = hz.f = 0;
     hz.prog = L.code + uni(M->code_off) + ZH_CODE_PAD;
     hz.len = uni(M->hcomp_len);
@@ -260,9 +309,9 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
     hz.r = S.r;
     uint32_t h0 = 0;                                   // h[0] = z.H(0)
 
-    int pp_state = 0, pp_hsize = 0;
+    int pp_state = 0, pp_hsize = 0;                    // PostProcessor (PostProcessor.cs:12-16)
     uint32_t pp_len = 0;
-    Vm pz;
+    Vm &pz = S.pz;
     pz.a = pz.b = pz.c = pz.d = pz.f = 0;
     pz.prog = nullptr; pz.len = 0;
     pz.m = slot_mem + uni64(M->pm_off); pz.mmask = (uint32_t)((1ull << uni(M->pm)) - 1);
@@ -274,17 +323,19 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
     d.low = 1; d.high = 0xFFFFFFFFu; d.curr = 0;
 
     OutBuf ob;
-    ob.base = L.out + b_out_off; ob.cap = b_out_cap; ob.len = 0; ob.flushed = 0;
-    Sink sink;                                         // used only when a PCOMP program emits output
+    ob.base = L.out + b_out_off; ob.cap = b_out_cap; ob.len = 0; ob.stored = 0; ob.word = 0; ob.park = 0;
+    out_room(ob);
+    Sink &sink = S.sink;                               // used only when a PCOMP program emits output
     sink.out = ob.base; sink.cap = ob.cap; sink.len = 0;
 
+    __syncthreads();
     InBuf in;
-    in.stream = L.in; in.total = L.in_total;
+    in.stream = L.in; in.total = L.in_total; in.cbase = 0; in.k = 0; in.avail = 0; in.cur = 0;
 
     int failed = 0;
     for (uint32_t s = 0; s < n_seg; ++s) {
       const uint32_t si = first_seg + s;
-      const uint64_t produced0 = pp_state == 5 ? sink.len : ob.len;
+      const uint64_t produced0 = pp_state == 5 ? uni64(sink.len) : ob.len;
       int status = 0;
       if (failed) {
         if (lane == 0) {
@@ -296,107 +347,137 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
         continue;
       }
       const uint64_t seg_off = uni64(L.segs[si].in_off);
-      in_open(in, seg_off, lane);
+      in_seek(in, seg_off, lane);
 
-      for (;;) {                                       // one decoded byte per iteration
-        // ---- Decoder.decompress prologue (Decoder.cs:36-45)
+      // One decoded byte: Decoder.decompress() (Decoder.cs:32-56) with predict/update folded in.
+      // Returns 0..255, -1 at EOS, -2 on error (status set).
+      auto decode_byte = [&]() __attribute__((always_inline)) -> int {
         if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
-        if (d.curr == 0)
-          for (int i = 0; i < 4; ++i) d.curr = d.curr << 8 | (uint32_t)in_get(in, lane);
-        int y = dec_step(d, 0, in, lane);              // EOS flag
-        if (y < 0) { status = y; break; }
+        // ---- Decoder.decompress prologue (Decoder.cs:36-45)
+        if (UNLIKELY(d.curr == 0)) {
+          uint32_t cu = 0;
+          for (int i = 0; i < 4; ++i) cu = cu << 8 | (uint32_t)in_get(in, lane);
+          d.curr = uni(cu);
+        }
+        uint32_t bad = 0, rn, j = 0;
+        d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr);   // folds away where already scalar
+        ZH_DEC_STEP(d, 0u, j, bad, rn);                // EOS flag: p = 0
+        if (UNLIKELY(bad)) { status = ZH_E_CORRUPT; return -2; }
+        if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane)) { status = ZH_E_EOF; return -2; } }
         int c;
-        if (y) {
-          if (d.curr != 0) { status = ZH_E_EOS; break; }
+        if (UNLIKELY(j)) {
+          if (d.curr != 0) { status = ZH_E_EOS; return -2; }
           c = -1;
         } else {
           ZH_STAMP(0);
           // ---- probabilities for every context this byte can reach
           const uint32_t hm = h0 & cm_mask;
           const uint32_t w = hm >> 9, lo9 = hm & 511, g0 = lo9 >> 4, x = lo9 & 15;
-          const uint32_t slot = win_get(w, tag, stamp, clock++, S, table, lane);
+          const uint64_t hit = __ballot(tag == w);
+          uint32_t slot;
+          if (LIKELY(hit != 0)) slot = (uint32_t)__builtin_ctzll(hit);
+          else slot = win_miss(w, tag, fifo, S, table, lane);
           ZH_STAMP(1);
           uint32_t *win = &S.win[slot][0];
-          const uint32_t gb = g0 ^ 16;                 // groups of the second nibble: gb ^ n
-          const uint32_t ia = (g0 << 4) | (lane & 15);
-          uint32_t ib[4], cmb[4], pb[4];
-          uint32_t cma = win[ia];
+          // lane (g, j) reads position j ^ x of a group: first nibble group g0, second nibble groups (g0^16)^n
+          const uint32_t pos = l15 ^ x;
+          const uint32_t ia = (g0 << 4) | pos;
+          const uint32_t ib0 = ((((g0 ^ 16) & 16) | lgrp) << 4) | pos;   // + 64*k entries for k = 0..3
+          const uint32_t cma = win[ia];
+          uint32_t cmb[4], pb[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            ib[k] = (((gb & 16) | ((lane >> 4) + 4 * k)) << 4) | (lane & 15);
-            cmb[k] = win[ib[k]];
-          }
-          uint32_t pa = S.fused[cma >> 17];
+          for (int k = 0; k < 4; ++k) cmb[k] = win[ib0 + 64 * k];
+          const uint32_t pa = (uint32_t)S.fused[cma >> 17] << 16;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) pb[k] = S.fused[cmb[k] >> 17];
-
+          for (int k = 0; k < 4; ++k) pb[k] = (uint32_t)S.fused[cmb[k] >> 17] << 16;
           ZH_STAMP(2);
-          // ---- first nibble
-          uint32_t j = 1;
+
+          // ---- first nibble: context j lives in lane j
+          // A failed renormalisation (end of stream) is recorded, not branched on: the coder
+          // keeps running on garbage for at most a nibble; the FIRST error is what is reported.
+          uint32_t err = 0;
+          j = 1;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            y = dec_step(d, rdlane(pa, x ^ j), in, lane);
-            if (y < 0) break;
-            j = j * 2 + (uint32_t)y;
+            const uint32_t ps = rdlane(pa, j);
+            ZH_DEC_STEP(d, ps, j, bad, rn);
+            if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane) && !err) err = bad ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF; }
           }
-          if (y < 0) { status = y; break; }
+          if (UNLIKELY(err | bad)) { status = err ? -(int)err : ZH_E_CORRUPT; return -2; }
           ZH_STAMP(3);
           const uint32_t n1 = j & 15;
-          // ---- second nibble: group (gb ^ n1), held by lanes (ga&3)*16.. in register ga>>2
-          const uint32_t ga = (gb ^ n1) & 15, kb = ga >> 2, lb = (ga & 3) * 16;
-          uint32_t psel = kb == 0 ? pb[0] : kb == 1 ? pb[1] : kb == 2 ? pb[2] : pb[3];
+          // ---- second nibble: group ((g0 ^ n1) & 15) is held by lane group (ga & 3), register ga >> 2
+          const uint32_t ga = uni((g0 ^ n1) & 15), kb = ga >> 2, lb = (ga & 3) * 16;
+          const uint32_t psel = kb == 0 ? pb[0] : kb == 1 ? pb[1] : kb == 2 ? pb[2] : pb[3];
           uint32_t j2 = 1;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            y = dec_step(d, rdlane(psel, lb + (x ^ j2)), in, lane);
-            if (y < 0) break;
-            j2 = j2 * 2 + (uint32_t)y;
+            const uint32_t ps = rdlane(psel, lb + j2);
+            ZH_DEC_STEP(d, ps, j2, bad, rn);
+            if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane) && !err) err = bad ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF; }
           }
-          if (y < 0) { status = y; break; }
+          if (UNLIKELY(err | bad)) { status = err ? -(int)err : ZH_E_CORRUPT; return -2; }
           ZH_STAMP(4);
           const uint32_t n2 = j2 & 15;
           c = (int)(n1 << 4 | n2);
 
-          // ---- train the 8 visited entries (Predictor.train), lanes in parallel
+          // ---- train the 8 visited entries (Predictor.train), one pass over the lanes:
+          // lane group (ga&3) updates the second-nibble entries, group (ga&3)^1 the first-nibble ones.
           {
-            // first nibble: lane<16 holds position (lane), i.e. slot j = lane ^ x
-            uint32_t jj = (lane & 15) ^ x;
-            uint32_t tt = 31 - __clz((int)(jj | 1));                       // bit position 0..3
-            bool vis = lane < 16 && jj != 0 && jj == ((16 | n1) >> (4 - tt));
-            uint32_t yy = (n1 >> (3 - tt)) & 1;
-            uint32_t cnt = cma & 0x3ff;
-            int err = (int)(yy * 32767) - (int)(cma >> 17);
-            uint32_t nv = cma + (((uint32_t)err * (uint32_t)S.dt[cnt]) & 0xFFFFFC00u) + (cnt < limit);
-            if (vis) win[ia] = nv;
-            // second nibble
-            uint32_t cmsel = kb == 0 ? cmb[0] : kb == 1 ? cmb[1] : kb == 2 ? cmb[2] : cmb[3];
-            uint32_t isel = kb == 0 ? ib[0] : kb == 1 ? ib[1] : kb == 2 ? ib[2] : ib[3];
-            bool vis2 = (lane >> 4) == (ga & 3) && jj != 0 && jj == ((16 | n2) >> (4 - tt));
-            uint32_t yy2 = (n2 >> (3 - tt)) & 1;
-            uint32_t cnt2 = cmsel & 0x3ff;
-            int err2 = (int)(yy2 * 32767) - (int)(cmsel >> 17);
-            uint32_t nv2 = cmsel + (((uint32_t)err2 * (uint32_t)S.dt[cnt2]) & 0xFFFFFC00u) + (cnt2 < limit);
-            if (vis2) win[isel] = nv2;
+            const bool isb = lgrp == (ga & 3);
+            const bool isa = lgrp == ((ga & 3) ^ 1);
+            const uint32_t cmsel = kb == 0 ? cmb[0] : kb == 1 ? cmb[1] : kb == 2 ? cmb[2] : cmb[3];
+            const uint32_t cm = isb ? cmsel : cma;
+            const uint32_t idx = isb ? ib0 + 64 * kb : ia;
+            const uint32_t nib = isb ? n2 : n1;
+            const bool vis = (isa || isb) && l15 != 0 && l15 == ((16 | nib) >> lsh_vis);
+            const uint32_t yy = (nib >> lsh_y) & 1;
+            const uint32_t cnt = cm & 0x3ff;
+            const int err = (int)(yy * 32767) - (int)(cm >> 17);
+            const uint32_t nv = cm + (((uint32_t)err * (uint32_t)S.dt[cnt]) & 0xFFFFFC00u) + (cnt < limit);
+            if (vis) win[idx] = nv;
           }
-
           ZH_STAMP(5);
+
           // ---- HCOMP (Predictor.cs:464-470): h[0] = H(0) after z.run(c)
-          if (hk == 1) h0 = (uint32_t)c << hshift;     // "a<<= K  *d=a  halt"
+          if (LIKELY(hk == ZH_HK_SHIFT)) h0 = (uint32_t)c << hshift;     // "a<<= K  *d=a  halt"
           else {
-            int rc = vm_run(hz, (uint32_t)c, nullptr, L.budget);
-            if (rc) { status = rc; break; }
+            int rc = (int)uni((uint32_t)vm_run(hz, (uint32_t)c, nullptr, L.budget));
+            if (rc) { status = rc; return -2; }
             h0 = uni(hz.h[0]);
           }
         }
 
+        return (int)uni((uint32_t)c);
+      };
+
+      for (;;) {
+        if (LIKELY(pp_state == 1)) {
+          // ---- steady state: PASS post-processor (PostProcessor.cs:49-51).  Nothing of the cold
+          // state machine below is live in this loop.
+          // Entering the steady-state loop: pin every loop-carried scalar to the scalar unit, so
+          // that LLVM's uniformity analysis sees a loop whose state is uniform on entry and on the
+          // back edge (a value it believes divergent anywhere outside would otherwise drag the
+          // whole loop onto the vector unit with exec-mask control flow).
+          d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr);
+          in.cbase = uni64(in.cbase); in.k = uni(in.k); in.avail = uni(in.avail);
+          ob.len = uni64(ob.len); ob.stored = uni64(ob.stored); ob.room = uni(ob.room); ob.word = uni(ob.word);
+          h0 = uni(h0); fifo = uni(fifo);
+          int c;
+          for (;;) {
+            c = (int)uni((uint32_t)decode_byte());
+            if (UNLIKELY(c < 0)) break;
+            out_put(ob, (uint32_t)c, lane);
+            ZH_STAMP(6);
+          }
+          break;                                          // EOS (c == -1) or error (c == -2)
+        }
+        int c = decode_byte();
+        if (c == -2) break;
         // ---- PostProcessor.write(c) (PostProcessor.cs:37-86)
-        if (pp_state == 1) {
-          if (c >= 0) out_put(ob, S, (uint32_t)c, lane);
-        } else if (pp_state == 5) {
-          if (ob.flushed < ob.len) out_flush(ob, S, lane, true);
-          int rc = 0;
-          if (lane == 0) rc = vm_run(pz, (uint32_t)c, &sink, L.budget);
-          rc = (int)uni((uint32_t)rc);
+        if (pp_state == 5) {
+          // every lane runs the program (same inputs, same stores): keeps control flow wave-uniform
+          int rc = (int)uni((uint32_t)vm_run(pz, (uint32_t)c, &sink, L.budget));
           if (rc) { status = rc; break; }
         } else if (pp_state == 0) {
           if (c < 0) { status = ZH_E_PP_EOS; break; }
@@ -412,7 +493,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
           pp_len = 0; pp_state = 4;
         } else {                                        // state 4: PCOMP bytes
           if (c < 0) { status = ZH_E_PP_EOS; break; }
-          if (lane == 0) pzbuf[pp_len] = (uint8_t)c;
+          pzbuf[pp_len] = (uint8_t)c;                  // all lanes store the same byte
           if ((int)++pp_len == pp_hsize) {
             __syncthreads();
             pz.prog = pzbuf; pz.len = pp_len;
@@ -420,21 +501,18 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
             pp_state = 5;
           }
         }
-        ZH_STAMP(6);
         if (c < 0) break;
       }
 
-      if (pp_state != 5) out_flush(ob, S, lane, true);
-      // a PCOMP program keeps its sink length in lane 0
+      if (pp_state != 5) out_flush(ob, lane);
       uint64_t produced = pp_state == 5 ? uni64(sink.len) : ob.len;
-      if (pp_state == 5) sink.len = produced;
       if (!status && produced > b_out_cap) status = ZH_E_OUTPUT_FULL;
       if (status && status != ZH_E_OUTPUT_FULL) failed = 1;
       if (lane == 0) {
         ZhSegResult res;
         res.status = status; res.pp_state = (uint32_t)pp_state;
         res.out_off = b_out_off + produced0; res.out_len = produced - produced0;
-        res.in_used = in.pos - seg_off;
+        res.in_used = in_pos(in) - seg_off;
         L.results[si] = res;
       }
     }
@@ -443,6 +521,8 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
     __syncthreads();
   }
 }
+
+}  // namespace
 
 extern "C" __global__ __launch_bounds__(64) void zh_decode_cm(ZhLaunch L, const uint16_t *__restrict__ fused_g) {
   __shared__ CmLds S;
