@@ -115,7 +115,7 @@ typedef struct zpaqhip_opts {
   uint32_t struct_size;       /* = sizeof(zpaqhip_opts) */
   uint32_t verify_sha1;       /* 1: check stored SHA-1 of every segment (Decompresser.cs:183-191 contract) */
   uint32_t max_concurrent;    /* blocks in flight per launch; 0 = auto (memory-bound) */
-  uint32_t kernel;            /* 0 auto; 1 force generic kernel; 2 force lane-parallel kernel */
+  uint32_t kernel;            /* 0 auto; 1 force the generic (one-lane) kernel; 3 prefer the lane-per-component kernel */
   uint64_t zpaql_budget;      /* max ZPAQL instructions per run() call; 0 = default (1<<32) */
   uint64_t reserved[4];
 } zpaqhip_opts;
@@ -132,7 +132,7 @@ typedef struct zpaqhip_stats {
   uint64_t model_bytes;       /* per-block model state (sum over decoded blocks) */
   uint32_t launches;          /* decode kernel launches */
   uint32_t concurrent;        /* blocks in flight per launch */
-  uint32_t kernel_kind;       /* 1 generic, 2 lane-parallel */
+  uint32_t kernel_kind;       /* most specialised kernel used: 1 generic, 2 single-CM lanes, 3 lane-per-component */
   uint32_t reserved;
 } zpaqhip_stats;
 

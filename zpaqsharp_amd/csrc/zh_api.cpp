@@ -20,6 +20,7 @@
 
 extern "C" hipError_t zh_launch_generic(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream);
+extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream);
 
 
@@ -252,9 +253,12 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
 
   // ---- kernel family per block (opts.kernel == 1 forces the generic kernel)
   auto family = [&](size_t k) -> uint32_t {
-    return opts.kernel == 1 ? ZH_FAM_GENERIC : (models[bd[k].model].kind & 255u);
+    uint32_t f = models[bd[k].model].kind & 255u;
+    if (opts.kernel == 1) f = ZH_FAM_GENERIC;              // force the generic kernel
+    if (opts.kernel == 3 && f == ZH_FAM_CM1) f = ZH_FAM_CHAIN;   // force the lane-per-component kernel
+    return f;
   };
-  std::vector<std::vector<uint32_t>> groups(2);
+  std::vector<std::vector<uint32_t>> groups(ZH_NFAM);
   for (size_t k = 0; k < sel.size(); ++k) groups[family(k)].push_back((uint32_t)k);
 
   size_t free_b = 0, total_b = 0;
@@ -275,9 +279,9 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
   HIPCHK(hipMemsetAsync(c->queue.p, 0, 256, stream));
 
   // arena: sized for the most demanding group
-  uint32_t slots_of[2] = {0, 0};
-  uint64_t stride_of[2] = {256, 256}, arena_need = 0;
-  for (uint32_t g = 0; g < 2; ++g) {
+  uint32_t slots_of[ZH_NFAM] = {0, 0, 0};
+  uint64_t stride_of[ZH_NFAM] = {256, 256, 256}, arena_need = 0;
+  for (uint32_t g = 0; g < ZH_NFAM; ++g) {
     if (groups[g].empty()) continue;
     for (uint32_t k : groups[g]) stride_of[g] = std::max<uint64_t>(stride_of[g], models[bd[k].model].arena_bytes);
     uint64_t max_slots = mem_budget / stride_of[g];
@@ -290,8 +294,8 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
 
   std::vector<ZhBlockDesc> bd_sorted;
   bd_sorted.reserve(sel.size());
-  size_t base_of[2] = {0, 0};
-  for (uint32_t g = 0; g < 2; ++g) {
+  size_t base_of[ZH_NFAM] = {0, 0, 0};
+  for (uint32_t g = 0; g < ZH_NFAM; ++g) {
     // Longest block first: the work queue then balances the tail (LPT order).
     std::stable_sort(groups[g].begin(), groups[g].end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
     base_of[g] = bd_sorted.size();
@@ -301,7 +305,7 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
 
   uint32_t launches = 0, slots = 0, kind_used = 0;
   HIPCHK(hipEventRecord(c->ev0, stream));
-  for (uint32_t g = 0; g < 2; ++g) {
+  for (uint32_t g = 0; g < ZH_NFAM; ++g) {
     if (groups[g].empty()) continue;
     ZhLaunch L;
     memset(&L, 0, sizeof L);
@@ -316,13 +320,14 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     L.arena = (uint8_t *)c->arena.p;
     L.arena_stride = stride_of[g];
     L.tables = (const ZhTables *)c->tables.p;
-    L.queue = (uint32_t *)c->queue.p + 16 * g;          // one work-queue head per launch
+    L.queue = (uint32_t *)c->queue.p + 8 * g;           // one work-queue head per launch
     L.n_blocks = (uint32_t)groups[g].size();
     L.budget = opts.zpaql_budget;
     const bool prof = getenv("ZPAQHIP_PROF") != nullptr;   // diagnostic build with in-kernel stamps
     if (prof) { L.debug = (uint64_t *)c->queue.p + 16; HIPCHK(hipMemsetAsync(L.debug, 0, 64, stream)); }
     if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, (const uint16_t *)c->fused.p, slots_of[g], stream));
     else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, (const uint16_t *)c->fused.p, slots_of[g], stream));
+    else if (g == ZH_FAM_CHAIN) HIPCHK(zh_launch_chain(&L, slots_of[g], stream));
     else HIPCHK(zh_launch_generic(&L, slots_of[g], stream));
     ++launches;
     slots = std::max(slots, slots_of[g]);

@@ -1,0 +1,569 @@
+// zh_chain.hip — lane-per-component decode kernel: component chains of up to 64
+// components (ICM / ISSE / MATCH / MIX / MIX2 / SSE / AVG / CM / CONST), i.e. the
+// reference's built-in min / mid / max models (BASELINE configs 3-5).
+//
+// One wavefront owns one block; lane i owns component i of the model
+// (Predictor.cs:245-475 runs them one after another, here they run side by side):
+//
+//  * All table traffic of a bit is issued by all components at once.  The pieces a
+//    component can touch during a NIBBLE are fetched once per nibble into a 64-byte
+//    per-lane LDS slot: the 16-byte hash row of an ICM/ISSE (Predictor.find,
+//    Predictor.cs:550-567 — the three candidate rows are probed in parallel) or the
+//    64-byte line of a CM.  Bit-history -> probability / weight tables of ICM and
+//    ISSE (1-2 KiB each) live in LDS for the whole block.
+//  * The inter-component dependencies (ISSE/AVG/MIX2/SSE/MIX inputs) are resolved
+//    level by level; the host computes each component's level.  Cross-lane operands
+//    travel by ds_bpermute; a MIX is a wave reduction over its input lanes (DPP), and
+//    each input lane owns, loads, trains and stores ITS weight of the mixer row
+//    (Predictor.cs:302-316, :427-439) — coalesced row traffic, no serial loop.
+//  * The final probability goes through v_readlane to the scalar unit, which runs
+//    the arithmetic decoder step shared with zh_cm.hip (Decoder.cs:136-158).
+//  * MATCH verifies a candidate match with all 64 lanes comparing history bytes and
+//    one ballot (Predictor.cs:403-405 is a serial loop of up to 255 steps).
+//  * HCOMP / PCOMP run on the scalar core (zh_core.h) with H and M in LDS when small.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "zh_core.h"
+#include "zh_dev.h"
+#include "zh_model.h"
+
+using namespace zhcore;
+using namespace zhdev;
+
+namespace {
+
+constexpr int kSmallWords = 16384;        // LDS pool for ICM (256 words) / ISSE (512 words) tables
+constexpr int kHWords = 256;              // HCOMP H kept in LDS when 2^hh <= 256
+constexpr int kMBytes = 4096;             // HCOMP M kept in LDS when 2^hm <= 4096
+constexpr int kMaxMix = 4;
+
+struct MixInfo {                          // one MIX component, wave-uniform
+  uint32_t lane, j0, m, level;
+  uint32_t *cm;
+};
+
+struct alignas(16) ChainLds {
+  ZhTables t;
+  uint32_t small[kSmallWords];
+  uint8_t slot[64][64];                   // per-lane nibble cache (hash row or CM line)
+  uint32_t hreg[kHWords];
+  uint8_t mreg[kMBytes];
+  uint32_t r[256], pr[256];
+  MixInfo mix[kMaxMix];
+  Vm hz, pz;
+  Sink sink;
+};
+static_assert(sizeof(ChainLds) <= 163840, "LDS budget");
+
+__device__ __forceinline__ int clampk(int x, int lo, int hi) { return x < lo ? lo : x > hi ? hi : x; }
+
+// Wave-wide integer sum (DPP row shifts + row broadcasts); result is wave-uniform.
+__device__ __forceinline__ int wave_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+  return (int)rdlane((uint32_t)v, 63);
+}
+
+// Per-lane view of one component (Component.cs:18-57 + its header arguments).
+struct Lane {
+  uint32_t type, a0, a1, a2, a3, a4, level;
+  uint8_t *cm, *ht;                       // arena tables
+  uint32_t cm_mask, ht_mask;
+  uint32_t sbase;                         // word offset of the ICM/ISSE table in S.small
+  uint32_t limit, cxt, a, b, c;           // Component state
+  uint32_t h;                             // h[i]
+  int p, pj, pk;                          // own prediction and the inputs it was computed from
+  int w0, w1;                             // ISSE weights / MIX2 weight / SSE entries of this bit
+  uint32_t mbyte, mcur;                   // MATCH: predicted byte, byte being assembled
+  int mw[kMaxMix];                        // weights of this lane in each mixer row
+  uint32_t memb;                          // bit q set: this lane feeds mixer q
+  bool rowvalid;                          // slot holds a row/line that must be written back
+};
+
+// Predictor.find (Predictor.cs:550-567) for one lane: probe the three candidate rows,
+// pick / recycle one, and leave it in the lane's LDS slot.  Returns the row offset.
+__device__ __forceinline__ uint32_t find_row_lds(uint8_t *ht, uint32_t ht_mask, int sizebits, uint32_t cxt,
+                                                 uint8_t *slot) {
+  const uint32_t chk = (cxt >> sizebits) & 255;
+  const uint32_t h0 = (cxt * 16u) & (ht_mask - 15u), h1 = h0 ^ 16, h2 = h0 ^ 32;
+  const uint4 r0 = *reinterpret_cast<const uint4 *>(ht + h0);
+  const uint4 r1 = *reinterpret_cast<const uint4 *>(ht + h1);
+  const uint4 r2 = *reinterpret_cast<const uint4 *>(ht + h2);
+  uint32_t sel;
+  uint4 row;
+  if ((r0.x & 255) == chk) { sel = h0; row = r0; }
+  else if ((r1.x & 255) == chk) { sel = h1; row = r1; }
+  else if ((r2.x & 255) == chk) { sel = h2; row = r2; }
+  else {
+    const uint32_t p0 = (r0.x >> 8) & 255, p1 = (r1.x >> 8) & 255, p2 = (r2.x >> 8) & 255;
+    if (p0 <= p1 && p0 <= p2) sel = h0;
+    else if (p1 < p2) sel = h1;
+    else sel = h2;
+    row = make_uint4(chk, 0, 0, 0);
+  }
+  *reinterpret_cast<uint4 *>(slot) = row;
+  return sel;
+}
+
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
+  __shared__ ChainLds S;
+  const uint32_t lane = threadIdx.x;
+
+  {  // model-independent tables -> LDS
+    const uint4 *src = reinterpret_cast<const uint4 *>(L.tables);
+    uint4 *dst = reinterpret_cast<uint4 *>(&S.t);
+    for (uint32_t i = lane; i < sizeof(ZhTables) / 16; i += 64) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  uint8_t *slot_mem = L.arena + (uint64_t)blockIdx.x * L.arena_stride;
+  uint8_t *myslot = &S.slot[lane][0];
+
+  for (;;) {
+    uint32_t bi = 0;
+    if (lane == 0) bi = atomicAdd(L.queue, 1u);
+    bi = uni((uint32_t)__shfl((int)bi, 0));
+    if (bi >= L.n_blocks) break;                       // every wave reaches this exit
+
+    const ZhBlockDesc *bdp = &L.blocks[bi];
+    const uint32_t model_i = uni(bdp->model);
+    const uint32_t first_seg = uni(bdp->first_seg), n_seg = uni(bdp->n_seg);
+    const uint64_t b_out_off = uni64(bdp->out_off), b_out_cap = uni64(bdp->out_cap);
+    const ZhModel *M = &L.models[model_i];
+    const uint32_t n = uni(M->n), depth = uni(M->depth);
+    const uint32_t hh = uni(M->hh), hmb = uni(M->hm);
+
+    // ---- Predictor.init (Predictor.cs:82-171): arena tables by all lanes, component by component
+    for (uint32_t i = 0; i < n; ++i) {
+      const ZhComp &cp = M->comp[i];
+      const uint32_t type = uni(cp.type);
+      uint8_t *cm = slot_mem + uni64(cp.cm_off), *ht = slot_mem + uni64(cp.ht_off);
+      const uint64_t cmb = uni64(cp.cm_bytes), htb = uni64(cp.ht_bytes);
+      uint4 pat = make_uint4(0, 0, 0, 0);
+      bool fill_cm = false;
+      if (type == ZH_CM) { pat = make_uint4(0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u); fill_cm = true; }
+      else if (type == ZH_MATCH) fill_cm = true;
+      else if (type == ZH_MIX2) { pat = make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u); fill_cm = true; }
+      else if (type == ZH_MIX) { const uint32_t w = 65536u / uni(cp.arg[2]); pat = make_uint4(w, w, w, w); fill_cm = true; }
+      if (fill_cm) { uint4 *q = reinterpret_cast<uint4 *>(cm); for (uint64_t k = lane; k < cmb / 16; k += 64) q[k] = pat; }
+      if (type == ZH_SSE) {                              // squash((j&31)*64-992)<<17 | start, period 32 entries
+        const uint32_t start = uni(cp.arg[2]);
+        uint4 *q = reinterpret_cast<uint4 *>(cm);
+        for (uint64_t k = lane; k < cmb / 16; k += 64) {
+          const uint32_t j = (uint32_t)(k * 4) & 31;
+          uint4 v;
+          v.x = (uint32_t)S.t.squash[(j + 0) * 64 - 992 + 2048] << 17 | start;
+          v.y = (uint32_t)S.t.squash[(j + 1) * 64 - 992 + 2048] << 17 | start;
+          v.z = (uint32_t)S.t.squash[(j + 2) * 64 - 992 + 2048] << 17 | start;
+          v.w = (uint32_t)S.t.squash[(j + 3) * 64 - 992 + 2048] << 17 | start;
+          q[k] = v;
+        }
+      }
+      if (type == ZH_ICM || type == ZH_ISSE || type == ZH_MATCH) {
+        uint4 *q = reinterpret_cast<uint4 *>(ht);
+        for (uint64_t k = lane; k < htb / 16; k += 64) q[k] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    {  // VM memories: arena tail (H, M, PCOMP H/M/program) zeroed; LDS copies zeroed
+      const uint64_t h_off = uni64(M->h_off), tail = uni64(M->arena_bytes) - h_off;
+      uint4 *z = reinterpret_cast<uint4 *>(slot_mem + h_off);
+      for (uint64_t i = lane; i < tail / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
+      for (uint32_t i = lane; i < 256; i += 64) { S.r[i] = 0; S.pr[i] = 0; S.hreg[i] = 0; }
+      for (uint32_t i = lane; i < kMBytes / 4; i += 64) reinterpret_cast<uint32_t *>(S.mreg)[i] = 0;
+    }
+
+    __syncthreads();
+    // ---- this lane's component
+    Lane me;
+    {
+      const bool act = lane < n;
+      const ZhComp *cp = &M->comp[act ? lane : 0];
+      me.type = act ? cp->type : (uint32_t)ZH_NONE;
+      me.a0 = cp->arg[0]; me.a1 = cp->arg[1]; me.a2 = cp->arg[2]; me.a3 = cp->arg[3]; me.a4 = cp->arg[4];
+      me.level = cp->level;
+      me.cm = slot_mem + cp->cm_off; me.ht = slot_mem + cp->ht_off;
+      me.cm_mask = cp->cm_mask; me.ht_mask = cp->ht_mask;
+      me.sbase = (uint32_t)cp->small_unit * 256u;
+      me.limit = me.cxt = me.a = me.b = me.c = 0; me.h = 0;
+      me.p = me.pj = me.pk = 0; me.w0 = me.w1 = 0; me.mbyte = me.mcur = 0; me.memb = 0; me.rowvalid = false;
+      for (int q = 0; q < kMaxMix; ++q) me.mw[q] = 0;
+      switch (me.type) {                                 // scalar parts of Predictor.init
+        case ZH_CONS: me.p = ((int)me.a0 - 128) * 4; break;
+        case ZH_CM: me.limit = me.a1 * 4; break;
+        case ZH_ICM:
+          me.limit = 1023;
+          for (uint32_t j = 0; j < 256; ++j) {
+            const uint32_t n0 = S.t.ns[j * 4 + 2], n1 = S.t.ns[j * 4 + 3];
+            S.small[me.sbase + j] = ((n1 * 2 + 1) << 22) / (n0 + n1 + 1);                 // StateTable.cminit
+          }
+          break;
+        case ZH_ISSE:
+          for (uint32_t j = 0; j < 256; ++j) {
+            const uint32_t n0 = S.t.ns[j * 4 + 2], n1 = S.t.ns[j * 4 + 3];
+            const uint32_t ci = ((n1 * 2 + 1) << 22) / (n0 + n1 + 1);
+            S.small[me.sbase + 2 * j] = 1u << 15;
+            S.small[me.sbase + 2 * j + 1] = (uint32_t)clamp512k(S.t.stretch[ci >> 8] * 1024);
+          }
+          break;
+        case ZH_MATCH: me.ht[0] = 1; break;
+        case ZH_MIX2: case ZH_MIX: me.c = me.cm_mask + 1; break;
+        case ZH_SSE: me.limit = me.a3 * 4; break;
+        default: break;
+      }
+    }
+    // mixers (wave-uniform table in LDS) and which of them each lane feeds
+    uint32_t nmix = 0;
+    {
+      uint64_t mm = __ballot(me.type == ZH_MIX);
+      while (mm && nmix < kMaxMix) {
+        const uint32_t ml = (uint32_t)__builtin_ctzll(mm);
+        mm &= mm - 1;
+        const uint32_t j0 = rdlane(me.a1, ml), m = rdlane(me.a2, ml);
+        if (lane == ml) { S.mix[nmix].lane = ml; S.mix[nmix].j0 = j0; S.mix[nmix].m = m; S.mix[nmix].level = me.level; S.mix[nmix].cm = (uint32_t *)me.cm; }
+        if (lane >= j0 && lane < j0 + m) me.memb |= 1u << nmix;
+        ++nmix;
+      }
+    }
+    __syncthreads();
+
+    // HCOMP machine (ZPAQL.cs:1010-1026): H and M in LDS when they fit
+    Vm &hz = S.hz;
+    hz.a = hz.b = hz.c = hz.d = hz.f = 0;
+    hz.prog = L.code + uni(M->code_off) + ZH_CODE_PAD;
+    hz.len = uni(M->hcomp_len);
+    hz.hmask = (uint32_t)((1ull << hh) - 1); hz.mmask = (uint32_t)((1ull << hmb) - 1);
+    hz.h = (1u << hh) <= (uint32_t)kHWords && hh < 31 ? S.hreg : reinterpret_cast<uint32_t *>(slot_mem + uni64(M->h_off));
+    hz.m = hmb < 31 && (1u << hmb) <= (uint32_t)kMBytes ? S.mreg : slot_mem + uni64(M->m_off);
+    hz.r = S.r;
+    const uint32_t *Hptr = hz.h;
+    const uint32_t hmask = hz.hmask;
+
+    int pp_state = 0, pp_hsize = 0;                    // PostProcessor (PostProcessor.cs:12-16)
+    uint32_t pp_len = 0;
+    Vm &pz = S.pz;
+    pz.a = pz.b = pz.c = pz.d = pz.f = 0;
+    pz.prog = nullptr; pz.len = 0;
+    pz.m = slot_mem + uni64(M->pm_off); pz.mmask = (uint32_t)((1ull << uni(M->pm)) - 1);
+    pz.h = reinterpret_cast<uint32_t *>(slot_mem + uni64(M->ph_off)); pz.hmask = (uint32_t)((1ull << uni(M->ph)) - 1);
+    pz.r = S.pr;
+    uint8_t *pzbuf = slot_mem + uni64(M->pz_off) + ZH_CODE_PAD;
+
+    Dec d;
+    d.low = 1; d.high = 0xFFFFFFFFu; d.curr = 0;
+    OutBuf ob;
+    ob.base = L.out + b_out_off; ob.cap = b_out_cap; ob.len = 0; ob.stored = 0; ob.word = 0; ob.park = 0;
+    out_room(ob);
+    Sink &sink = S.sink;
+    sink.out = ob.base; sink.cap = ob.cap; sink.len = 0;
+    __syncthreads();
+    InBuf in;
+    in.stream = L.in; in.total = L.in_total; in.cbase = 0; in.k = 0; in.avail = 0; in.cur = 0;
+
+    uint32_t c8 = 1, hmap4 = 1;                        // Predictor.cs:20-21
+
+    // Start of a nibble (c8 == 1 or 16 <= c8 < 32): write the old row/line back, fetch the new one.
+    auto nibble_refresh = [&]() __attribute__((always_inline)) {
+      if (me.type == ZH_ICM || me.type == ZH_ISSE) {
+        if (me.rowvalid) *reinterpret_cast<uint4 *>(me.ht + me.c) = *reinterpret_cast<const uint4 *>(myslot);
+        me.c = find_row_lds(me.ht, me.ht_mask, (int)me.a0 + 2, me.h + 16u * c8, myslot);
+        me.rowvalid = true;
+      } else if (me.type == ZH_CM) {
+        uint4 *g = reinterpret_cast<uint4 *>(me.cm) + (size_t)me.c * 4;
+        uint4 *l = reinterpret_cast<uint4 *>(myslot);
+        if (me.rowvalid) { g[0] = l[0]; g[1] = l[1]; g[2] = l[2]; g[3] = l[3]; }
+        me.c = ((me.h ^ hmap4) & me.cm_mask) >> 4;     // 16-entry line of this nibble
+        g = reinterpret_cast<uint4 *>(me.cm) + (size_t)me.c * 4;
+        const uint4 x0 = g[0], x1 = g[1], x2 = g[2], x3 = g[3];
+        l[0] = x0; l[1] = x1; l[2] = x2; l[3] = x3;
+        me.rowvalid = true;
+      }
+    };
+
+    int failed = 0;
+    for (uint32_t s = 0; s < n_seg; ++s) {
+      const uint32_t si = first_seg + s;
+      const uint64_t produced0 = pp_state == 5 ? uni64(sink.len) : ob.len;
+      int status = 0;
+      if (failed) {
+        if (lane == 0) {
+          ZhSegResult res;
+          res.status = ZH_E_SKIPPED; res.pp_state = (uint32_t)pp_state; res.out_off = b_out_off + produced0; res.out_len = 0;
+          res.in_used = 0;
+          L.results[si] = res;
+        }
+        continue;
+      }
+      const uint64_t seg_off = uni64(L.segs[si].in_off);
+      in_seek(in, seg_off, lane);
+      if (s == 0) nibble_refresh();                    // first nibble of the block (h[] = 0)
+
+      for (;;) {                                       // one decoded byte per iteration
+        // ---- Decoder.decompress prologue (Decoder.cs:36-45)
+        if (UNLIKELY(d.curr == 0)) {
+          uint32_t cu = 0;
+          for (int i = 0; i < 4; ++i) cu = cu << 8 | (uint32_t)in_get(in, lane);
+          d.curr = uni(cu);
+        }
+        uint32_t bad = 0, rn, j = 0, err = 0;
+        d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr);
+        ZH_DEC_STEP(d, 0u, j, bad, rn);                // EOS flag: p = 0
+        if (UNLIKELY(bad)) { status = ZH_E_CORRUPT; break; }
+        if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane)) { status = ZH_E_EOF; break; } }
+        int c;
+        if (UNLIKELY(j)) {
+          if (d.curr != 0) { status = ZH_E_EOS; break; }
+          c = -1;
+        } else {
+          for (int bit = 0; bit < 8; ++bit) {
+            const uint32_t hm15 = hmap4 & 15;
+            // ================= predict, level 0 (Predictor.cs:259-343) =================
+            uint32_t rows[kMaxMix] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {      // mixer rows: every input lane loads its own weight
+              if (q >= nmix) break;
+              const uint32_t ml = uni(S.mix[q].lane), j0 = uni(S.mix[q].j0), m = uni(S.mix[q].m);
+              const uint32_t rowv = ((me.h + (c8 & me.a4)) & (me.c - 1)) * m;          // valid in the mixer lane
+              rows[q] = rdlane(rowv, ml);
+              if (me.memb >> q & 1) me.mw[q] = (int)S.mix[q].cm[rows[q] + (lane - j0)];
+            }
+            switch (me.type) {
+              case ZH_CM: {
+                me.cxt = (me.h ^ hmap4) & 15;
+                const uint32_t v = reinterpret_cast<const uint32_t *>(myslot)[me.cxt];
+                me.p = S.t.stretch[v >> 17];
+                break;
+              }
+              case ZH_ICM: {
+                me.cxt = myslot[hm15];
+                me.p = S.t.stretch[S.small[me.sbase + me.cxt] >> 8];
+                break;
+              }
+              case ZH_ISSE: {
+                me.cxt = myslot[hm15];
+                me.w0 = (int)S.small[me.sbase + me.cxt * 2];
+                me.w1 = (int)S.small[me.sbase + me.cxt * 2 + 1];
+                break;
+              }
+              case ZH_MATCH:
+                if (me.a == 0) me.p = 0;
+                else {
+                  me.c = (me.mbyte >> (7 - me.cxt)) & 1;
+                  me.p = S.t.stretch[(S.t.dt2k[me.a] * (1 - 2 * (int)me.c)) & 32767];
+                }
+                break;
+              case ZH_MIX2:
+                me.cxt = (me.h + (c8 & me.a4)) & (me.c - 1);
+                me.w0 = reinterpret_cast<const uint16_t *>(me.cm)[me.cxt];
+                break;
+              default: break;
+            }
+            // ================= predict, dependent levels =================
+            for (uint32_t lv = 1; lv <= depth; ++lv) {
+              const int pj = __shfl(me.p, (int)(me.type == ZH_AVG ? me.a0 : me.a1));
+              const int pk = __shfl(me.p, (int)(me.type == ZH_AVG ? me.a1 : me.a2));
+              if (me.level == lv) {
+                me.pj = pj; me.pk = pk;
+                switch (me.type) {
+                  case ZH_ISSE: me.p = clamp2k((me.w0 * pj + me.w1 * 64) >> 16); break;
+                  case ZH_AVG: me.p = (pj * (int)me.a2 + pk * (256 - (int)me.a2)) >> 8; break;
+                  case ZH_MIX2: me.p = (me.w0 * pj + (65536 - me.w0) * pk) >> 16; break;
+                  case ZH_SSE: {
+                    me.cxt = (me.h + c8) * 32u;
+                    int pq = clampk(pj + 992, 0, 1983);
+                    const int wt = pq & 63;
+                    pq >>= 6;
+                    me.cxt += (uint32_t)pq;
+                    const uint32_t *cm = reinterpret_cast<const uint32_t *>(me.cm);
+                    const uint32_t e0 = cm[me.cxt & me.cm_mask], e1 = cm[(me.cxt + 1) & me.cm_mask];
+                    me.p = S.t.stretch[((e0 >> 10) * (uint32_t)(64 - wt) + (e1 >> 10) * (uint32_t)wt) >> 13];
+                    me.cxt += (uint32_t)(wt >> 5);
+                    me.w0 = (int)((wt >> 5) ? e1 : e0);          // the entry train() will update
+                    break;
+                  }
+                  default: break;
+                }
+              }
+#pragma unroll
+              for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {
+                if (q >= nmix) break;
+                if (uni(S.mix[q].level) != lv) continue;
+                const int term = (me.memb >> q & 1) ? (me.mw[q] >> 8) * me.p : 0;
+                const int sum = wave_sum(term);
+                if (lane == uni(S.mix[q].lane)) me.p = clamp2k(sum >> 8);
+              }
+            }
+            // ================= decode the bit =================
+            const uint32_t pr = rdlane((uint32_t)S.t.squash[me.p + 2048], n - 1);
+            const uint32_t ps = (pr * 2 + 1) << 16;
+            ZH_DEC_STEP(d, ps, j, bad, rn);
+            if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane) && !err) err = bad ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF; }
+            const int y = (int)(j & 1);
+
+            // ================= update (Predictor.cs:363-461) =================
+#pragma unroll
+            for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {      // MIX: error from the mixer lane, weights in the input lanes
+              if (q >= nmix) break;
+              const uint32_t ml = uni(S.mix[q].lane), j0 = uni(S.mix[q].j0);
+              const int e = (y * 32767 - (int)S.t.squash[me.p + 2048]) * (int)me.a3 >> 4;   // valid in the mixer lane
+              const int eq = (int)rdlane((uint32_t)e, ml);
+              if (me.memb >> q & 1) {
+                me.mw[q] = clamp512k(me.mw[q] + ((eq * me.p + (1 << 12)) >> 13));
+                S.mix[q].cm[rows[q] + (lane - j0)] = (uint32_t)me.mw[q];
+              }
+            }
+            switch (me.type) {
+              case ZH_CM: {
+                uint32_t *pn = &reinterpret_cast<uint32_t *>(myslot)[me.cxt];
+                const uint32_t v = *pn, cnt = v & 0x3ff;
+                const int e = y * 32767 - (int)(v >> 17);
+                *pn = v + (((uint32_t)e * (uint32_t)S.t.dt[cnt]) & 0xFFFFFC00u) + (cnt < me.limit);
+                break;
+              }
+              case ZH_SSE: {
+                const uint32_t v = (uint32_t)me.w0, cnt = v & 0x3ff;
+                const int e = y * 32767 - (int)(v >> 17);
+                reinterpret_cast<uint32_t *>(me.cm)[me.cxt & me.cm_mask] =
+                    v + (((uint32_t)e * (uint32_t)S.t.dt[cnt]) & 0xFFFFFC00u) + (cnt < me.limit);
+                break;
+              }
+              case ZH_ICM: {
+                myslot[hm15] = S.t.ns[me.cxt * 4 + y];
+                uint32_t *pn = &S.small[me.sbase + me.cxt];
+                *pn += (uint32_t)((int)(y * 32767 - (int)(*pn >> 8)) >> 2);
+                break;
+              }
+              case ZH_ISSE: {
+                const int e = y * 32767 - (int)S.t.squash[me.p + 2048];
+                S.small[me.sbase + me.cxt * 2] = (uint32_t)clamp512k(me.w0 + ((e * me.pj + (1 << 12)) >> 13));
+                S.small[me.sbase + me.cxt * 2 + 1] = (uint32_t)clamp512k(me.w1 + ((e + 16) >> 5));
+                myslot[hm15] = S.t.ns[me.cxt * 4 + y];
+                break;
+              }
+              case ZH_MATCH:
+                if ((int)me.c != y) me.a = 0;
+                me.mcur = (me.mcur * 2 + (uint32_t)y) & 255;
+                ++me.cxt;                                // finished at the byte boundary below
+                break;
+              case ZH_MIX2: {
+                const int e = (y * 32767 - (int)S.t.squash[me.p + 2048]) * (int)me.a3 >> 5;
+                int w = me.w0 + ((e * (me.pj - me.pk) + (1 << 12)) >> 13);
+                w = clampk(w, 0, 65535);
+                reinterpret_cast<uint16_t *>(me.cm)[me.cxt] = (uint16_t)w;
+                break;
+              }
+              default: break;
+            }
+            // ---- c8 / hmap4 bookkeeping (Predictor.cs:463-474)
+            c8 = c8 * 2 + (uint32_t)y;
+            if (c8 >= 256) break;                        // byte complete: handled below
+            if (c8 >= 16 && c8 < 32) {
+              hmap4 = (hmap4 & 0xf) << 5 | (uint32_t)y << 4 | 1;
+              nibble_refresh();
+            } else hmap4 = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + (uint32_t)y) & 0xf);
+          }
+          if (UNLIKELY(err | bad)) { status = err ? -(int)err : ZH_E_CORRUPT; break; }
+          c = (int)(c8 - 256);
+
+          // ---- MATCH at the byte boundary (Predictor.cs:391-410)
+          {
+            const bool ism = me.type == ZH_MATCH;
+            uint32_t need = 0;
+            if (ism) {
+              me.cxt = 0;
+              me.ht[me.limit & me.ht_mask] = (uint8_t)me.mcur;   // the assembled byte; ht(0)=1 is overwritten like the reference
+              me.mcur = 0;
+              me.limit = (me.limit + 1) & me.ht_mask;
+            }
+            if (ism) {                                     // still with the h[i] of the byte just coded (update0 runs before z.run)
+              uint32_t *cm = reinterpret_cast<uint32_t *>(me.cm);
+              if (me.a == 0) {
+                me.b = me.limit - cm[me.h & me.cm_mask];
+                need = (me.b & me.ht_mask) != 0;
+              } else me.a += me.a < 255;
+              cm[me.h & me.cm_mask] = me.limit;
+            }
+            // h[] for the next byte: z.run(c), then H(i) (Predictor.cs:465-469)
+            const int rc = (int)uni((uint32_t)vm_run(hz, (uint32_t)c, nullptr, L.budget));
+            if (rc) { status = rc; break; }
+            me.h = Hptr[lane & hmask];
+            uint64_t nm = __ballot(need != 0);
+            while (nm) {                                   // verify candidates with the whole wave
+              const uint32_t ml = (uint32_t)__builtin_ctzll(nm);
+              nm &= nm - 1;
+              const uint32_t lim = rdlane(me.limit, ml), off = rdlane(me.b, ml), msk = rdlane(me.ht_mask, ml);
+              const uint8_t *hp = reinterpret_cast<const uint8_t *>(uni64((uint64_t)(uintptr_t)__shfl((long long)(uintptr_t)me.ht, (int)ml)));
+              uint32_t len = 0;
+              for (uint32_t base = 0; base < 256; base += 64) {
+                const uint32_t t = base + lane;
+                const bool eq = t < 255 && hp[(lim - t - 1) & msk] == hp[(lim - t - off - 1) & msk];
+                const uint64_t mism = __ballot(!eq);
+                if (mism) { len += (uint32_t)__builtin_ctzll(mism); break; }
+                len += 64;
+              }
+              if (lane == ml) me.a = len > 255 ? 255 : len;
+            }
+            if (ism) me.mbyte = me.ht[(me.limit - me.b) & me.ht_mask];
+          }
+          hmap4 = 1; c8 = 1;
+          nibble_refresh();
+        }
+
+        // ---- PostProcessor.write(c) (PostProcessor.cs:37-86)
+        c = (int)uni((uint32_t)c);
+        if (LIKELY(pp_state == 1)) {
+          if (LIKELY(c >= 0)) out_put(ob, (uint32_t)c, lane);
+        } else if (pp_state == 5) {
+          const int rc = (int)uni((uint32_t)vm_run(pz, (uint32_t)c, &sink, L.budget));
+          if (rc) { status = rc; break; }
+        } else if (pp_state == 0) {
+          if (c < 0) { status = ZH_E_PP_EOS; break; }
+          pp_state = c + 1;
+          if (pp_state > 2) { status = ZH_E_PP_TYPE; break; }
+        } else if (pp_state == 2) {
+          if (c < 0) { status = ZH_E_PP_EOS; break; }
+          pp_hsize = c; pp_state = 3;
+        } else if (pp_state == 3) {
+          if (c < 0) { status = ZH_E_PP_EOS; break; }
+          pp_hsize += c * 256;
+          if (pp_hsize < 1) { status = ZH_E_PP_EMPTY; break; }
+          pp_len = 0; pp_state = 4;
+        } else {                                        // state 4: PCOMP bytes
+          if (c < 0) { status = ZH_E_PP_EOS; break; }
+          pzbuf[pp_len] = (uint8_t)c;
+          if ((int)++pp_len == pp_hsize) {
+            __syncthreads();
+            pz.prog = pzbuf; pz.len = pp_len;
+            pz.a = pz.b = pz.c = pz.d = pz.f = 0;
+            pp_state = 5;
+          }
+        }
+        if (c < 0) break;
+      }
+
+      if (pp_state != 5) out_flush(ob, lane);
+      const uint64_t produced = pp_state == 5 ? uni64(sink.len) : ob.len;
+      if (!status && produced > b_out_cap) status = ZH_E_OUTPUT_FULL;
+      if (status && status != ZH_E_OUTPUT_FULL) failed = 1;
+      if (lane == 0) {
+        ZhSegResult res;
+        res.status = status; res.pp_state = (uint32_t)pp_state;
+        res.out_off = b_out_off + produced0; res.out_len = produced - produced0;
+        res.in_used = in_pos(in) - seg_off;
+        L.results[si] = res;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL(zh_decode_chain, dim3(grid), dim3(64), 0, stream, *L);
+  return hipGetLastError();
+}

@@ -33,9 +33,11 @@
 #include <stdint.h>
 
 #include "zh_core.h"
+#include "zh_dev.h"
 #include "zh_model.h"
 
 using namespace zhcore;
+using namespace zhdev;
 
 namespace {
 
@@ -52,161 +54,6 @@ struct alignas(16) CmLds {
   Sink sink;                              // output of a PCOMP program (lane 0 only)
 };
 static_assert(sizeof(CmLds) <= 163840, "LDS budget");
-
-#define LIKELY(x) __builtin_expect(!!(x), 1)
-#define UNLIKELY(x) __builtin_expect(!!(x), 0)
-
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint64_t uni64(uint64_t v) {
-  return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
-}
-__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t lane) {
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane);
-}
-// park[lane] = val with both operands scalar: the lane select has to go through M0 (one
-// constant-bus operand per VALU instruction on gfx9); M0 is saved and restored.
-__device__ __forceinline__ uint32_t wrlane(uint32_t val, uint32_t lane, uint32_t park) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-               : "+v"(park), "=&s"(keep) : "s"(uni(val)), "s"(uni(lane)));
-  return park;
-}
-
-// NOTE on 64-bit values in this file: the scalar unit has no ordered 64-bit compare, so any
-// `a < b` on uint64_t is selected onto the vector unit and turns a uniform branch into an
-// exec-mask dance.  The per-byte paths therefore only ever compare 32-bit counters.
-
-// ---- compressed-byte reader: one 256-byte chunk of the stream, a dword per lane ----
-struct InBuf {
-  const uint8_t *stream;                  // whole stream (uniform)
-  uint64_t total;                         // stream length = EOF (Decoder.get reads the caller's Reader,
-                                          // which does not stop at a segment end: Decoder.cs:112-122)
-  uint64_t cbase;                         // stream offset of the chunk in `cur` (multiple of 4)
-  uint32_t k;                             // cursor inside the chunk: position = cbase + k
-  uint32_t avail;                         // valid bytes in the chunk (<= 256)
-  uint32_t cur;                           // per-lane dword of the chunk
-};
-
-__device__ __forceinline__ uint64_t in_pos(const InBuf &in) { return in.cbase + in.k; }
-
-__device__ __forceinline__ void in_seek(InBuf &in, uint64_t pos, uint32_t lane) {
-  in.cbase = pos & ~3ull;
-  in.k = (uint32_t)(pos & 3);
-  const uint64_t left = in.total > in.cbase ? in.total - in.cbase : 0;
-  in.avail = left < 256 ? (uint32_t)left : 256u;
-  const uint32_t o = 4u * lane;           // whole-dword reads; the stream buffer is readable up to its 4-byte rounded end
-  in.cur = o < in.avail ? *reinterpret_cast<const uint32_t *>(in.stream + in.cbase + o) : 0u;
-}
-
-// Decoder.get(): next coded byte, or -1 at the end of the stream.
-__device__ __forceinline__ int in_get(InBuf &in, uint32_t lane) {
-  if (UNLIKELY(in.k >= in.avail)) {
-    in_seek(in, in_pos(in), lane);
-    if (in.k >= in.avail) return -1;
-  }
-  const uint32_t k = in.k++;
-  return (int)((rdlane(in.cur, k >> 2) >> ((k & 3) * 8)) & 255);
-}
-
-// ---- plaintext writer: dwords assembled on the SALU, parked in a VGPR, 256-byte stores ----
-struct OutBuf {
-  uint8_t *base;                          // block's output base (uniform)
-  uint64_t cap, len;                      // capacity / bytes produced (len counts past cap)
-  uint64_t stored;                        // bytes already in HBM
-  uint32_t room;                          // bytes that may still be stored (clamped to 32 bits, refreshed per chunk)
-  uint32_t word;                          // bytes of the current dword (scalar)
-  uint32_t park;                          // per-lane: dword (vpos>>2)&63 of the current 256-byte chunk
-};
-
-__device__ __forceinline__ void out_room(OutBuf &o) {
-  const uint64_t r = o.cap > o.len ? o.cap - o.len : 0;
-  o.room = r > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)r;
-}
-
-// Writes bytes [stored, lim) out of the parked chunk.  vpos = (base & 255) + position, so the
-// chunk in `park` is 256-byte aligned in memory and lane l holds its bytes 4l..4l+3.
-__device__ __forceinline__ void out_flush(OutBuf &o, uint32_t lane) {
-  const uint64_t lim = o.len < o.cap ? o.len : o.cap;
-  if (lim > o.stored) {
-    const uint32_t phase = (uint32_t)((uintptr_t)o.base & 255);
-    const uint64_t vend = phase + lim;
-    uint32_t park = o.park;
-    if (vend & 3) park = wrlane(o.word, (uint32_t)((vend >> 2) & 63), park);
-    const uint64_t v0 = phase + o.stored, v1 = vend;                 // virtual byte range to write
-    const uint64_t chunk_v = (v1 - 1) & ~255ull;                     // the parked chunk (holds the last byte)
-    const uint64_t lv = chunk_v + 4ull * lane;                       // this lane's dword, virtual
-    uint8_t *dst = o.base + (lv - phase);
-    if (lv >= v0 && lv + 4 <= v1) *reinterpret_cast<uint32_t *>(dst) = park;
-    else
-      for (int i = 0; i < 4; ++i)
-        if (lv + i >= v0 && lv + i < v1) dst[i] = (uint8_t)(park >> (8 * i));
-    o.stored = lim;
-  }
-  out_room(o);
-}
-
-__device__ __forceinline__ void out_put(OutBuf &o, uint32_t c, uint32_t lane) {
-  const uint32_t v = (uint32_t)(uintptr_t)o.base + (uint32_t)o.len;  // low bits of the virtual position
-  ++o.len;
-  if (UNLIKELY(o.room == 0)) return;                                 // count-only past the capacity
-  --o.room;
-  const uint32_t sh = (v & 3) * 8;
-  o.word = sh ? (o.word | c << sh) : c;
-  if ((v & 3) == 3) {
-    o.park = wrlane(o.word, (v >> 2) & 63, o.park);
-    if (UNLIKELY((v & 255) == 255)) out_flush(o, lane);
-  }
-}
-
-struct Dec { uint32_t low, high, curr; };
-
-// One Decoder.decode step (Decoder.cs:136-158) on the scalar unit.
-//   ps  = p16 << 16 where p16 = predict()*2+1 (or 0 for the EOS flag): (range*p16)>>16 == mulhi(range, ps)
-//   j   = (j << 1) | y
-//   bad |= (curr < low || curr > high)            ("archive corrupted")
-//   rn  = (high ^ low) < 2^24  after the split    (renormalisation needed)
-#define ZH_DEC_STEP(d, ps, j, bad, rn)                                                              \
-  do {                                                                                              \
-    uint32_t r_, t_, off_, mid_, m1_, x_;                                                           \
-    asm volatile(                                                                                   \
-        "s_sub_u32 %[r], %[high], %[low]\n\t"                                                       \
-        "s_sub_u32 %[t], %[curr], %[low]\n\t"                                                       \
-        "s_mul_hi_u32 %[off], %[r], %[p]\n\t"                                                       \
-        "s_cmp_gt_u32 %[t], %[r]\n\t"                                                               \
-        "s_cselect_b32 %[bd], 1, %[bd]\n\t"                                                         \
-        "s_add_u32 %[mid], %[low], %[off]\n\t"                                                      \
-        "s_add_u32 %[m1], %[mid], 1\n\t"                                                            \
-        "s_cmp_le_u32 %[t], %[off]\n\t"                                                             \
-        "s_cselect_b32 %[high], %[mid], %[high]\n\t"                                                \
-        "s_cselect_b32 %[low], %[low], %[m1]\n\t"                                                   \
-        "s_addc_u32 %[jj], %[jj], %[jj]\n\t"                                                        \
-        "s_xor_b32 %[x], %[high], %[low]\n\t"                                                       \
-        "s_cmp_lt_u32 %[x], 0x1000000\n\t"                                                          \
-        "s_cselect_b32 %[rn_], 1, 0"                                                                \
-        : [low] "+s"(d.low), [high] "+s"(d.high), [curr] "+s"(d.curr), [jj] "+s"(j), [bd] "+s"(bad), \
-          [rn_] "=s"(rn),                                                                           \
-          [r] "=&s"(r_), [t] "=&s"(t_), [off] "=&s"(off_), [mid] "=&s"(mid_), [m1] "=&s"(m1_),      \
-          [x] "=&s"(x_)                                                                             \
-        : [p] "s"(ps)                                                                               \
-        : "scc");                                                                                   \
-  } while (0)
-
-// Renormalisation loop of Decoder.decode (Decoder.cs:148-156).  Returns 0 or ZH_E_EOF.
-__device__ __forceinline__ int dec_renorm(Dec &d, InBuf &in, uint32_t lane) {
-  int rc = 0;
-  uint32_t low = d.low, high = d.high, curr = d.curr;
-  do {
-    high = high << 8 | 255;
-    low = low << 8;
-    low = low ? low : 1u;                 // low += (low == 0)
-    int c = in_get(in, lane);
-    if (c < 0) { rc = ZH_E_EOF; break; }
-    curr = curr << 8 | (uint32_t)c;
-  } while ((high ^ low) < 0x1000000u);
-  // this rare path may be selected onto the vector unit; hand the state back as scalars
-  d.low = uni(low); d.high = uni(high); d.curr = uni(curr);
-  return (int)uni((uint32_t)rc);
-}
 
 // Window cache miss: pick the next FIFO victim, write it back, load window w.
 __device__ __forceinline__ uint32_t win_miss(uint32_t w, uint32_t &tag, uint32_t &fifo, CmLds &S, uint32_t *table,

@@ -12,6 +12,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "zh_host.h"
 
 namespace zh {
@@ -345,8 +347,36 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
   code.insert(code.end(), hdr + cp, hdr + len);
   code.insert(code.end(), ZH_CODE_PAD, 0);
   while (code.size() & 15) code.push_back(0);
+  // ---- dependency levels and LDS placement for the lane-per-component kernel
+  {
+    uint32_t units = 0, nmix = 0, depth = 0;
+    bool ok = m.n >= 1 && m.n <= 64;
+    for (uint32_t i = 0; i < m.n; ++i) {
+      ZhComp &c = m.comp[i];
+      const uint8_t *a = c.arg;
+      uint32_t lv = 0;
+      auto in = [&](uint32_t j) { lv = std::max<uint32_t>(lv, m.comp[j].level + 1u); };
+      switch (c.type) {
+        case ZH_AVG: in(a[0]); in(a[1]); break;
+        case ZH_MIX2: in(a[1]); in(a[2]); break;
+        case ZH_MIX: for (uint32_t j = a[1]; j < (uint32_t)a[1] + a[2]; ++j) in(j); ++nmix; break;
+        case ZH_ISSE: in(a[1]); break;
+        case ZH_SSE: in(a[1]); break;
+        default: break;
+      }
+      c.level = (uint8_t)lv;
+      depth = std::max(depth, lv);
+      c.small_unit = 0;
+      if (c.type == ZH_ICM || c.type == ZH_ISSE) {
+        if (units > 255) ok = false; else c.small_unit = (uint8_t)units;
+        units += c.type == ZH_ICM ? 1 : 2;
+      }
+      if (c.type == ZH_CM && a[0] < 4) ok = false;       // a nibble's 16 entries must be distinct
+    }
+    m.depth = depth;
+    m.kind = (ok && units <= 64 && nmix <= 4) ? ZH_FAM_CHAIN : ZH_FAM_GENERIC;
+  }
   // ---- specialisation the kernels may use (never changes results)
-  m.kind = ZH_FAM_GENERIC;
   if (m.n == 1 && m.comp[0].type == ZH_CM && m.comp[0].arg[0] >= 9) {
     m.kind = ZH_FAM_CM1;
     const uint8_t *hc = hdr + cp;                       // "a<<= K  *d=a  halt" (D is 0 at every entry)

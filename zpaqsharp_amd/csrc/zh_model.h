@@ -25,6 +25,8 @@ enum ZhCompType : uint8_t {  // LibZPAQ.cs:51-63
 
 #define ZH_FAM_GENERIC 0u        // zh_generic.hip
 #define ZH_FAM_CM1 1u            // zh_cm.hip: n == 1, one CM with >= 9 size bits
+#define ZH_FAM_CHAIN 2u          // zh_chain.hip: lane-per-component, n <= 64
+#define ZH_NFAM 3u
 #define ZH_HK_GENERIC 0u         // interpret HCOMP
 #define ZH_HK_SHIFT 1u           // HCOMP == "a<<= K  *d=a  halt" with D == 0: H[0] = c << K
 
@@ -44,7 +46,8 @@ enum ZhCompType : uint8_t {  // LibZPAQ.cs:51-63
 struct ZhComp {            // one component of a model (Component.cs:18-57 + header args)
   uint8_t type;            // ZhCompType
   uint8_t arg[5];          // header bytes cp[1..5]
-  uint16_t pad;
+  uint8_t level;           // dependency depth: 0 = no prediction inputs, else 1 + max(level of inputs)
+  uint8_t small_unit;      // zh_chain: offset of the ICM/ISSE state table in the LDS pool, in 256-word units
   uint32_t cm_mask;        // (#elements of cm / a16) - 1 where the reference indexes masked
   uint32_t ht_mask;        // (#bytes of ht) - 1
   uint64_t cm_off;         // byte offset of cm (u32[]) or a16 (u16[]) in the arena slot
@@ -60,7 +63,7 @@ struct ZhModel {
   uint32_t hcomp_len;      // program bytes incl. trailing 0
   uint32_t kind;           // host-chosen specialisation: bits 0-7 kernel family (ZH_FAM_*),
                            // bits 8-15 HCOMP form (ZH_HK_*), bits 16-23 its parameter
-  uint32_t pad;
+  uint32_t depth;          // max component level
   uint64_t h_off, m_off;   // HCOMP H (u32[1<<hh]) and M (u8[1<<hm])
   uint64_t ph_off, pm_off; // PCOMP H and M
   uint64_t pz_off;         // PCOMP program buffer, ZH_PCOMP_BUF bytes
