@@ -389,3 +389,61 @@ def test_cpp_mirror_of_the_reference_api(ctx, tmp_path):
     out = subprocess.check_output([str(exe), str(tmp_path / "in.zpaq"), str(tmp_path / "out.bin")]).decode()
     assert out.split() == ["OK", str(len(a) + len(b)), "1", "2", "2"], out
     assert (tmp_path / "out.bin").read_bytes() == a + b
+
+
+@pytest.mark.parametrize("model,kind", [("min", 3), ("mid", 3), ("max", 3), ("max+e8e9", 3), ("l1", 2)])
+def test_kernel_selection_and_cross_kernel_agreement(ctx, model, kind):
+    data = util.x86ish(40000, 3) if "e8e9" in model else util.text(40000, 3)
+    s = synth.compress_block(model, data)
+    auto = ctx.decompress(s, verify_sha1=True).tobytes()
+    assert ctx.stats().kernel_kind == kind                      # the specialised kernel really ran
+    generic = ctx.decompress(s, verify_sha1=True, kernel=1).tobytes()
+    assert ctx.stats().kernel_kind == 1
+    assert auto == generic == data == oracle.decompress(s)
+    if model == "l1":                                           # a single CM also runs on the lane-per-component kernel
+        chain = ctx.decompress(s, verify_sha1=True, kernel=3).tobytes()
+        assert ctx.stats().kernel_kind == 3 and chain == data
+
+
+def test_random_component_chains(ctx):
+    """Random COMP lists exercising every component type and arbitrary input wiring on the
+    lane-per-component kernel, against the oracle (encoder: libzpaqgen, decoder: oracle + GPU)."""
+    rng = np.random.default_rng(12345)
+    data = util.text(6000, seed=21) + util.x86ish(2000, seed=22)
+    hcomp = "c++ *c=a b=c a=0 d= 0 hash *d=a b-- d++ hash *d=a b-- d++ hash *d=a d++ a=*c a<<= 8 *d=a d++ a=*c a*= 200 *d=a halt"
+    for trial in range(12):
+        n = int(rng.integers(2, 12))
+        comps = []
+        for i in range(n):
+            choices = ["cm", "icm", "match", "const"] if i == 0 else ["cm", "icm", "isse", "match", "avg", "mix2", "mix", "sse", "const"]
+            t = str(rng.choice(choices))
+            j, k = (int(rng.integers(0, i)), int(rng.integers(0, i))) if i else (0, 0)
+            if t == "cm":
+                comps.append(f"{i} cm {int(rng.integers(4, 18))} {int(rng.integers(1, 256))}")
+            elif t == "icm":
+                comps.append(f"{i} icm {int(rng.integers(0, 12))}")
+            elif t == "isse":
+                comps.append(f"{i} isse {int(rng.integers(0, 12))} {j}")
+            elif t == "match":
+                comps.append(f"{i} match {int(rng.integers(2, 16))} {int(rng.integers(8, 17))}")
+            elif t == "avg":
+                comps.append(f"{i} avg {j} {k} {int(rng.integers(0, 256))}")
+            elif t == "mix2":
+                comps.append(f"{i} mix2 {int(rng.integers(0, 10))} {j} {k} {int(rng.integers(1, 64))} {int(rng.choice([0, 255, 15]))}")
+            elif t == "mix":
+                m = int(rng.integers(1, i - j + 1))
+                comps.append(f"{i} mix {int(rng.integers(0, 10))} {j} {m} {int(rng.integers(1, 64))} {int(rng.choice([0, 255, 240]))}")
+            elif t == "sse":
+                lim = int(rng.integers(1, 256))
+                comps.append(f"{i} sse {int(rng.integers(0, 10))} {j} {int(rng.integers(0, min(255, lim * 4) + 1))} {lim}")
+            else:
+                comps.append(f"{i} const {int(rng.integers(0, 256))}")
+        if sum(c.split()[1] == "mix" for c in comps) > 4:
+            continue
+        cfg = f"comp 3 3 0 0 {n}\n" + "\n".join(comps) + f"\nhcomp {hcomp}\nend"
+        m = zpaql.assemble(cfg)
+        s = synth.compress_block(m, data)
+        assert oracle.decompress(s) == data, cfg
+        got = ctx.decompress(s, verify_sha1=True).tobytes()
+        assert got == data, cfg
+        assert ctx.stats().kernel_kind == 3, cfg

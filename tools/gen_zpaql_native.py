@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Ahead-of-time translation of known ZPAQL programs to HIP device functions.
+
+The reference's default build does not interpret ZPAQL: `ZPAQL.assemble()` and
+`Predictor.assemble_p()` emit x86 code for the block's HCOMP at run time
+(ZPAQL.cs:353-1008, "JIT").  A GPU cannot run an x86 JIT, and interpreting ZPAQL on a
+single wavefront costs hundreds of cycles per instruction, so the programs this repo
+knows (zpaqsharp_amd/models.py: the HCOMP of min / mid / max and the E8E9 PCOMP) are
+translated here, once, at build time, into straight C++ that hipcc compiles to native
+gfx950 code.  Any other program still runs on the interpreter (zh_core.h vm_run); the
+host picks the native routine only when the program bytes match exactly.
+
+Semantics follow ZPAQL.cs:1028-1251 instruction by instruction (one statement per
+ZPAQL instruction, labels at every instruction start, jumps as `goto`).
+
+Output: zpaqsharp_amd/csrc/zh_zpaql_native.h   (regenerate: python tools/gen_zpaql_native.py)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from zpaqsharp_amd import models, zpaql  # noqa: E402
+
+SRC = ["a", "b", "c", "d", "(uint32_t)M[b & mmask]", "(uint32_t)M[c & mmask]", "H[d & hmask]"]
+ALU = ["a += {s};", "a -= {s};", "a *= {s};", "{{ uint32_t s_ = {s}; a = s_ ? a / s_ : 0; }}",
+       "{{ uint32_t s_ = {s}; a = s_ ? a % s_ : 0; }}", "a &= {s};", "a &= ~({s});", "a |= {s};", "a ^= {s};",
+       "a <<= (({s}) & 31);", "a >>= (({s}) & 31);", "f = a == ({s});", "f = a < ({s});", "f = a > ({s});"]
+
+
+def store(ddd: int, val: str) -> str:
+    if ddd < 4:
+        return f"{'abcd'[ddd]} = {val};"
+    if ddd == 4:
+        return f"M[b & mmask] = (uint8_t)({val});"
+    if ddd == 5:
+        return f"M[c & mmask] = (uint8_t)({val});"
+    return f"H[d & hmask] = {val};"
+
+
+def translate(code: bytes, name: str) -> str:
+    """code = program bytes including the trailing END 0."""
+    n = len(code)
+
+    def length(pc):
+        op = code[pc]
+        return 3 if op == 255 else 2 if op & 7 == 7 else 1
+
+    def targets(pc):
+        """pcs control can reach from the instruction at pc (inside the program only)."""
+        op = code[pc]
+        arg = code[pc + 1] if pc + 1 < n else 0
+        nxt = pc + length(pc)
+        if op in (39, 47):
+            return [nxt, nxt + ((arg + 128) & 255) - 128]
+        if op == 63:
+            return [nxt + ((arg + 128) & 255) - 128]
+        if op == 255:
+            return [arg + 256 * (code[pc + 2] if pc + 2 < n else 0)]
+        if op == 56 or zpaql.is_error_op(op):
+            return []
+        return [nxt]
+
+    # every decode position control can reach (a jump may land inside a 2-byte instruction,
+    # which ZPAQL defines as decoding from there), in address order
+    valid, work = set(), [0]
+    while work:
+        pc = work.pop()
+        if pc in valid or not 0 <= pc < n:
+            continue
+        valid.add(pc)
+        work.extend(targets(pc))
+    starts = sorted(valid)
+
+    def jump(target: int, back_from: int) -> str:
+        if not 0 <= target < n:
+            return "return ZH_E_ZPAQL;"            # lands in the zero padding: opcode 0 = error
+        pre = "if (budget-- == 0) return ZH_E_BUDGET; " if target <= back_from else ""
+        return f"{pre}goto L{target};"
+
+    out = [f"// {name}: {' '.join(zpaql.disassemble_code(code[:-1]))}",
+           "template <class MP, class HP>",
+           f"ZH_HD inline int zh_native_{name}(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, uint32_t &f, uint32_t input,",
+           "    MP M, uint32_t mmask, HP H, uint32_t hmask, uint32_t *R, zhcore::Sink *out, uint64_t budget) {",
+           "  a = input;", "  (void)R; (void)out; (void)budget; (void)f;"]
+    for pc in starts:
+        op = code[pc]
+        arg = code[pc + 1] if pc + 1 < n else 0
+        nxt = pc + length(pc)
+        st = None
+        if op < 64:
+            ddd, x = op >> 3, op & 7
+            if x == 7:
+                off = ((arg + 128) & 255) - 128
+                if ddd < 4:
+                    st = f"{'abcd'[ddd]} = R[{arg}];"
+                elif ddd == 4:
+                    st = f"if (f) {{ {jump(nxt + off, pc)} }}"
+                elif ddd == 5:
+                    st = f"if (!f) {{ {jump(nxt + off, pc)} }}"
+                elif ddd == 6:
+                    st = f"R[{arg}] = a;"
+                else:
+                    st = jump(nxt + off, pc)
+            elif ddd == 7:
+                st = {0: "return 0;", 1: "if (out) zhcore::sink_put(*out, a & 255);",
+                      3: "a = (a + M[b & mmask] + 512u) * 773u;",
+                      4: "H[d & hmask] = (H[d & hmask] + a + 512u) * 773u;"}.get(x, "return ZH_E_ZPAQL;")
+            elif x > 4 or op == 0:
+                st = "return ZH_E_ZPAQL;"
+            else:
+                v = SRC[ddd]
+                if x == 0:                           # <>a ; *b / *c swap the low byte only
+                    if ddd in (4, 5):
+                        st = f"{{ uint32_t t_ = {v}; {store(ddd, 'a')} a = (a & ~255u) | t_; }}"
+                    else:
+                        st = f"{{ uint32_t t_ = {v}; {store(ddd, 'a')} a = t_; }}"
+                else:
+                    expr = {1: f"{v} + 1", 2: f"{v} - 1", 3: f"~{v}", 4: "0u"}[x]
+                    st = store(ddd, expr)
+        elif op == 255:
+            tgt = code[pc + 1] + 256 * (code[pc + 2] if pc + 2 < n else 0)
+            st = "return ZH_E_ZPAQL;" if tgt >= n else jump(tgt, pc)
+        else:
+            s = SRC[op & 7] if op & 7 < 7 else f"{arg}u"
+            if op < 128:
+                ddd = (op >> 3) & 7
+                st = "return ZH_E_ZPAQL;" if ddd == 7 else store(ddd, s)
+            else:
+                k = (op >> 3) & 15
+                st = ALU[k].format(s=s) if k < 14 else "return ZH_E_ZPAQL;"
+        fall = "" if (st.startswith("return") or st.startswith("goto") or st.startswith("if (budget")) else f" {jump(nxt, -1)}"
+        out.append(f"  L{pc}: {st}{fall}  // {zpaql.OPCODES[op] or 'error'}")
+    out.append("}")
+    return "\n".join(out)
+
+
+def main():
+    progs = [("hcomp_min", models.get("min").header), ("hcomp_mid", models.get("mid").header),
+             ("hcomp_max", models.get("max").header)]
+    items = []
+    for name, header in progs:
+        items.append((name, zpaql.parse_header(header)[5]))
+    items.append(("pcomp_e8e9", models.get("max+e8e9").pcomp))
+    lines = ["// zh_zpaql_native.h — GENERATED by tools/gen_zpaql_native.py from zpaqsharp_amd/models.py; do not edit.",
+             "// Native (ahead-of-time translated) forms of the ZPAQL programs this repo knows; see the generator.",
+             "#pragma once", "#include <stdint.h>", "#include <string.h>", "", '#include "zh_core.h"', "",
+             "#if defined(__HIPCC__)", "#pragma clang diagnostic push", '#pragma clang diagnostic ignored "-Wunused-label"', "#endif", ""]
+    for name, code in items:
+        lines.append(translate(code, name))
+        lines.append("")
+    lines.append("#if defined(__HIPCC__)\n#pragma clang diagnostic pop\n#endif\n")
+    lines.append("// ids stored in ZhModel.kind (HCOMP) / matched on the device (PCOMP); 0 = interpret")
+    for i, (name, code) in enumerate(items):
+        lines.append(f"#define ZH_NATIVE_{name.upper()} {i + 2}u")
+    lines.append("")
+    for name, code in items:
+        lines.append(f"ZH_HD inline bool zh_native_is_{name}(const uint8_t *p, uint32_t len) {{")
+        lines.append(f"  if (len != {len(code)}u) return false;")
+        chunks = [" && ".join(f"p[{i}] == {code[i]}" for i in range(k, min(k + 8, len(code)))) for k in range(0, len(code), 8)]
+        lines.append("  return " + " &&\n         ".join(chunks) + ";")
+        lines.append("}")
+    lines.append("// Exact-match lookup (host or device).  Returns 0 when the program is not a known one.")
+    lines.append("ZH_HD inline uint32_t zh_native_lookup(const uint8_t *prog, uint32_t len) {")
+    for name, code in items:
+        lines.append(f"  if (zh_native_is_{name}(prog, len)) return ZH_NATIVE_{name.upper()};")
+    lines.append("  return 0;")
+    lines.append("}")
+    path = os.path.join(ROOT, "zpaqsharp_amd", "csrc", "zh_zpaql_native.h")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()

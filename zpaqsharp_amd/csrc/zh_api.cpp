@@ -21,6 +21,7 @@
 extern "C" hipError_t zh_launch_generic(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
+extern "C" hipError_t zh_launch_chain_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream);
 
 
@@ -327,6 +328,7 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     if (prof) { L.debug = (uint64_t *)c->queue.p + 16; HIPCHK(hipMemsetAsync(L.debug, 0, 64, stream)); }
     if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, (const uint16_t *)c->fused.p, slots_of[g], stream));
     else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, (const uint16_t *)c->fused.p, slots_of[g], stream));
+    else if (g == ZH_FAM_CHAIN && prof) HIPCHK(zh_launch_chain_prof(&L, slots_of[g], stream));
     else if (g == ZH_FAM_CHAIN) HIPCHK(zh_launch_chain(&L, slots_of[g], stream));
     else HIPCHK(zh_launch_generic(&L, slots_of[g], stream));
     ++launches;

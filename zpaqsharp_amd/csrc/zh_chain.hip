@@ -27,6 +27,7 @@
 #include "zh_core.h"
 #include "zh_dev.h"
 #include "zh_model.h"
+#include "zh_zpaql_native.h"
 
 using namespace zhcore;
 using namespace zhdev;
@@ -37,11 +38,9 @@ constexpr int kSmallWords = 16384;        // LDS pool for ICM (256 words) / ISSE
 constexpr int kHWords = 256;              // HCOMP H kept in LDS when 2^hh <= 256
 constexpr int kMBytes = 4096;             // HCOMP M kept in LDS when 2^hm <= 4096
 constexpr int kMaxMix = 4;
-
-struct MixInfo {                          // one MIX component, wave-uniform
-  uint32_t lane, j0, m, level;
-  uint32_t *cm;
-};
+constexpr int kCodeBytes = 2048;          // HCOMP program window kept in LDS when it fits
+constexpr int kPHWords = 256;             // PCOMP H in LDS when 2^ph <= 256
+constexpr int kPMBytes = 1024;            // PCOMP M in LDS when 2^pm <= 1024
 
 struct alignas(16) ChainLds {
   ZhTables t;
@@ -50,7 +49,9 @@ struct alignas(16) ChainLds {
   uint32_t hreg[kHWords];
   uint8_t mreg[kMBytes];
   uint32_t r[256], pr[256];
-  MixInfo mix[kMaxMix];
+  uint8_t code[kCodeBytes];
+  uint32_t phreg[kPHWords];
+  uint8_t pmreg[kPMBytes];
   Vm hz, pz;
   Sink sink;
 };
@@ -110,10 +111,10 @@ __device__ __forceinline__ uint32_t find_row_lds(uint8_t *ht, uint32_t ht_mask, 
   return sel;
 }
 
-}  // namespace
-
-extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
-  __shared__ ChainLds S;
+template <bool PROF>
+__device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S) {
+  uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t tprev = 0;
   const uint32_t lane = threadIdx.x;
 
   {  // model-independent tables -> LDS
@@ -177,6 +178,8 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
       for (uint64_t i = lane; i < tail / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
       for (uint32_t i = lane; i < 256; i += 64) { S.r[i] = 0; S.pr[i] = 0; S.hreg[i] = 0; }
       for (uint32_t i = lane; i < kMBytes / 4; i += 64) reinterpret_cast<uint32_t *>(S.mreg)[i] = 0;
+      for (uint32_t i = lane; i < kPHWords; i += 64) S.phreg[i] = 0;
+      for (uint32_t i = lane; i < kPMBytes / 4; i += 64) reinterpret_cast<uint32_t *>(S.pmreg)[i] = 0;
     }
 
     __syncthreads();
@@ -220,39 +223,82 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
     }
     // mixers (wave-uniform table in LDS) and which of them each lane feeds
     uint32_t nmix = 0;
+    uint32_t mx_lane[kMaxMix] = {0, 0, 0, 0}, mx_j0[kMaxMix] = {0, 0, 0, 0}, mx_m[kMaxMix] = {0, 0, 0, 0}, mx_lv[kMaxMix] = {0, 0, 0, 0};
+    uint32_t *mx_cm[kMaxMix] = {nullptr, nullptr, nullptr, nullptr};
     {
-      uint64_t mm = __ballot(me.type == ZH_MIX);
-      while (mm && nmix < kMaxMix) {
-        const uint32_t ml = (uint32_t)__builtin_ctzll(mm);
-        mm &= mm - 1;
-        const uint32_t j0 = rdlane(me.a1, ml), m = rdlane(me.a2, ml);
-        if (lane == ml) { S.mix[nmix].lane = ml; S.mix[nmix].j0 = j0; S.mix[nmix].m = m; S.mix[nmix].level = me.level; S.mix[nmix].cm = (uint32_t *)me.cm; }
-        if (lane >= j0 && lane < j0 + m) me.memb |= 1u << nmix;
-        ++nmix;
+      const uint64_t mm = __ballot(me.type == ZH_MIX);
+#pragma unroll
+      for (int q = 0; q < kMaxMix; ++q) {
+        uint64_t rest = mm;
+        for (int k = 0; k < q; ++k) rest &= rest - 1;             // drop the q lowest set bits
+        if (!rest) break;
+        const uint32_t ml = (uint32_t)__builtin_ctzll(rest);
+        mx_lane[q] = ml; mx_j0[q] = rdlane(me.a1, ml); mx_m[q] = rdlane(me.a2, ml); mx_lv[q] = rdlane(me.level, ml);
+        mx_cm[q] = reinterpret_cast<uint32_t *>(uni64((uint64_t)(uintptr_t)__shfl((long long)(uintptr_t)me.cm, (int)ml)));
+        if (lane >= mx_j0[q] && lane < mx_j0[q] + mx_m[q]) me.memb |= 1u << q;
+        nmix = (uint32_t)q + 1;
       }
+    }
+    // Level descriptors, one per level, held in lane `level` of lvl_desc:
+    //   bits 0-6  : the lane of the level's only non-MIX component, 64 = several, 65 = none
+    //   bits 8-11 : its type      bits 12-14 : 1 + index of the mixer evaluated at this level (0 = none)
+    //   bits 16-21: first input   bits 24-29 : second input
+    uint32_t lvl_desc = 65;
+    for (uint32_t lv = 1; lv <= depth && lv < 64; ++lv) {
+      const uint64_t at = __ballot(me.level == lv && me.type != ZH_MIX && lane < n);
+      uint32_t dsc = at ? 64u : 65u;
+      if (__builtin_popcountll(at) == 1) {
+        const uint32_t cl = (uint32_t)__builtin_ctzll(at);
+        const uint32_t sj = rdlane(me.type == ZH_AVG ? me.a0 : me.a1, cl), sk = rdlane(me.type == ZH_AVG ? me.a1 : me.a2, cl);
+        dsc = cl | rdlane(me.type, cl) << 8 | (sj & 63) << 16 | (sk & 63) << 24;
+      }
+#pragma unroll
+      for (int q = 0; q < kMaxMix; ++q)
+        if ((uint32_t)q < nmix && mx_lv[q] == lv && !(dsc >> 12 & 7)) dsc |= (uint32_t)(q + 1) << 12;
+      // a second mixer on the same level falls back to the generic test below
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int q = 0; q < kMaxMix; ++q) cnt += (uint32_t)q < nmix && mx_lv[q] == lv;
+      if (cnt > 1) dsc |= 7u << 12;
+      if (lane == lv) lvl_desc = dsc;
     }
     __syncthreads();
 
     // HCOMP machine (ZPAQL.cs:1010-1026): H and M in LDS when they fit
     Vm &hz = S.hz;
     hz.a = hz.b = hz.c = hz.d = hz.f = 0;
-    hz.prog = L.code + uni(M->code_off) + ZH_CODE_PAD;
     hz.len = uni(M->hcomp_len);
+    {
+      const uint8_t *gcode = L.code + uni(M->code_off);            // padded window: PAD | program | PAD
+      const uint32_t win = hz.len + 2 * ZH_CODE_PAD;
+      if (win <= (uint32_t)kCodeBytes) {
+        for (uint32_t i = lane; i < win; i += 64) S.code[i] = gcode[i];
+        hz.prog = S.code + ZH_CODE_PAD;
+      } else hz.prog = gcode + ZH_CODE_PAD;
+    }
     hz.hmask = (uint32_t)((1ull << hh) - 1); hz.mmask = (uint32_t)((1ull << hmb) - 1);
     hz.h = (1u << hh) <= (uint32_t)kHWords && hh < 31 ? S.hreg : reinterpret_cast<uint32_t *>(slot_mem + uni64(M->h_off));
     hz.m = hmb < 31 && (1u << hmb) <= (uint32_t)kMBytes ? S.mreg : slot_mem + uni64(M->m_off);
     hz.r = S.r;
     const uint32_t *Hptr = hz.h;
     const uint32_t hmask = hz.hmask;
+    const bool h_lds = hz.h == S.hreg && hz.m == S.mreg;
+    const uint32_t hnative = h_lds ? (uni(M->kind) >> 8) & 255 : 0;   // ahead-of-time translated HCOMP, if known
+    uint32_t ha = 0, hb = 0, hc = 0, hd = 0, hf = 0;                  // HCOMP registers A B C D F (wave-uniform)
 
     int pp_state = 0, pp_hsize = 0;                    // PostProcessor (PostProcessor.cs:12-16)
     uint32_t pp_len = 0;
     Vm &pz = S.pz;
     pz.a = pz.b = pz.c = pz.d = pz.f = 0;
     pz.prog = nullptr; pz.len = 0;
-    pz.m = slot_mem + uni64(M->pm_off); pz.mmask = (uint32_t)((1ull << uni(M->pm)) - 1);
-    pz.h = reinterpret_cast<uint32_t *>(slot_mem + uni64(M->ph_off)); pz.hmask = (uint32_t)((1ull << uni(M->ph)) - 1);
+    const uint32_t phb = uni(M->ph), pmb = uni(M->pm);
+    pz.mmask = (uint32_t)((1ull << pmb) - 1); pz.hmask = (uint32_t)((1ull << phb) - 1);
+    pz.m = pmb < 31 && (1u << pmb) <= (uint32_t)kPMBytes ? S.pmreg : slot_mem + uni64(M->pm_off);
+    pz.h = phb < 31 && (1u << phb) <= (uint32_t)kPHWords ? S.phreg : reinterpret_cast<uint32_t *>(slot_mem + uni64(M->ph_off));
     pz.r = S.pr;
+    const bool p_lds = pz.m == S.pmreg && pz.h == S.phreg;
+    uint32_t pnative = 0;                                 // set when the loaded PCOMP is a known program
+    uint32_t pa = 0, pb = 0, pc_ = 0, pd = 0, pf = 0;
     uint8_t *pzbuf = slot_mem + uni64(M->pz_off) + ZH_CODE_PAD;
 
     Dec d;
@@ -322,16 +368,16 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
           c = -1;
         } else {
           for (int bit = 0; bit < 8; ++bit) {
+            if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
             const uint32_t hm15 = hmap4 & 15;
             // ================= predict, level 0 (Predictor.cs:259-343) =================
             uint32_t rows[kMaxMix] = {0, 0, 0, 0};
 #pragma unroll
             for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {      // mixer rows: every input lane loads its own weight
               if (q >= nmix) break;
-              const uint32_t ml = uni(S.mix[q].lane), j0 = uni(S.mix[q].j0), m = uni(S.mix[q].m);
-              const uint32_t rowv = ((me.h + (c8 & me.a4)) & (me.c - 1)) * m;          // valid in the mixer lane
-              rows[q] = rdlane(rowv, ml);
-              if (me.memb >> q & 1) me.mw[q] = (int)S.mix[q].cm[rows[q] + (lane - j0)];
+              const uint32_t rowv = ((me.h + (c8 & me.a4)) & (me.c - 1)) * mx_m[q];    // valid in the mixer lane
+              rows[q] = rdlane(rowv, mx_lane[q]);
+              if (me.memb >> q & 1) me.mw[q] = (int)mx_cm[q][rows[q] + (lane - mx_j0[q])];
             }
             switch (me.type) {
               case ZH_CM: {
@@ -364,41 +410,80 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
                 break;
               default: break;
             }
+            ZH_STAMP(0);
             // ================= predict, dependent levels =================
             for (uint32_t lv = 1; lv <= depth; ++lv) {
-              const int pj = __shfl(me.p, (int)(me.type == ZH_AVG ? me.a0 : me.a1));
-              const int pk = __shfl(me.p, (int)(me.type == ZH_AVG ? me.a1 : me.a2));
-              if (me.level == lv) {
-                me.pj = pj; me.pk = pk;
-                switch (me.type) {
-                  case ZH_ISSE: me.p = clamp2k((me.w0 * pj + me.w1 * 64) >> 16); break;
-                  case ZH_AVG: me.p = (pj * (int)me.a2 + pk * (256 - (int)me.a2)) >> 8; break;
-                  case ZH_MIX2: me.p = (me.w0 * pj + (65536 - me.w0) * pk) >> 16; break;
-                  case ZH_SSE: {
-                    me.cxt = (me.h + c8) * 32u;
-                    int pq = clampk(pj + 992, 0, 1983);
-                    const int wt = pq & 63;
-                    pq >>= 6;
-                    me.cxt += (uint32_t)pq;
-                    const uint32_t *cm = reinterpret_cast<const uint32_t *>(me.cm);
-                    const uint32_t e0 = cm[me.cxt & me.cm_mask], e1 = cm[(me.cxt + 1) & me.cm_mask];
-                    me.p = S.t.stretch[((e0 >> 10) * (uint32_t)(64 - wt) + (e1 >> 10) * (uint32_t)wt) >> 13];
-                    me.cxt += (uint32_t)(wt >> 5);
-                    me.w0 = (int)((wt >> 5) ? e1 : e0);          // the entry train() will update
-                    break;
+              const uint32_t desc = rdlane(lvl_desc, lv & 63);
+              const uint32_t one = desc & 127, typ = (desc >> 8) & 15;
+              if (LIKELY(one < 64)) {
+                // a single component at this level: wave-uniform control flow, operands by v_readlane,
+                // every lane computes, only lane `one` keeps the result
+                const int pj = (int)rdlane((uint32_t)me.p, (desc >> 16) & 63);
+                const bool mine = lane == one;
+                if (LIKELY(typ == ZH_ISSE)) {
+                  const int v = clamp2k((me.w0 * pj + me.w1 * 64) >> 16);
+                  me.p = mine ? v : me.p; me.pj = mine ? pj : me.pj;
+                } else if (typ == ZH_MIX2) {
+                  const int pk = (int)rdlane((uint32_t)me.p, (desc >> 24) & 63);
+                  const int v = (me.w0 * pj + (65536 - me.w0) * pk) >> 16;
+                  me.p = mine ? v : me.p; me.pj = mine ? pj : me.pj; me.pk = mine ? pk : me.pk;
+                } else if (typ == ZH_AVG) {
+                  const int pk = (int)rdlane((uint32_t)me.p, (desc >> 24) & 63);
+                  const int v = (pj * (int)me.a2 + pk * (256 - (int)me.a2)) >> 8;
+                  me.p = mine ? v : me.p;
+                } else if (mine) {                       // SSE (Predictor.cs:327-340)
+                  me.pj = pj;
+                  me.cxt = (me.h + c8) * 32u;
+                  int pq = clampk(pj + 992, 0, 1983);
+                  const int wt = pq & 63;
+                  pq >>= 6;
+                  me.cxt += (uint32_t)pq;
+                  const uint32_t *cm = reinterpret_cast<const uint32_t *>(me.cm);
+                  const uint32_t e0 = cm[me.cxt & me.cm_mask], e1 = cm[(me.cxt + 1) & me.cm_mask];
+                  me.p = S.t.stretch[((e0 >> 10) * (uint32_t)(64 - wt) + (e1 >> 10) * (uint32_t)wt) >> 13];
+                  me.cxt += (uint32_t)(wt >> 5);
+                  me.w0 = (int)((wt >> 5) ? e1 : e0);    // the entry train() will update
+                }
+              } else if (one == 64) {
+                // several components at this level: every lane gathers its own operands (ds_bpermute)
+                const int pj = __shfl(me.p, (int)(me.type == ZH_AVG ? me.a0 : me.a1));
+                const int pk = __shfl(me.p, (int)(me.type == ZH_AVG ? me.a1 : me.a2));
+                if (me.level == lv) {
+                  me.pj = pj; me.pk = pk;
+                  switch (me.type) {
+                    case ZH_ISSE: me.p = clamp2k((me.w0 * pj + me.w1 * 64) >> 16); break;
+                    case ZH_AVG: me.p = (pj * (int)me.a2 + pk * (256 - (int)me.a2)) >> 8; break;
+                    case ZH_MIX2: me.p = (me.w0 * pj + (65536 - me.w0) * pk) >> 16; break;
+                    case ZH_SSE: {
+                      me.cxt = (me.h + c8) * 32u;
+                      int pq = clampk(pj + 992, 0, 1983);
+                      const int wt = pq & 63;
+                      pq >>= 6;
+                      me.cxt += (uint32_t)pq;
+                      const uint32_t *cm = reinterpret_cast<const uint32_t *>(me.cm);
+                      const uint32_t e0 = cm[me.cxt & me.cm_mask], e1 = cm[(me.cxt + 1) & me.cm_mask];
+                      me.p = S.t.stretch[((e0 >> 10) * (uint32_t)(64 - wt) + (e1 >> 10) * (uint32_t)wt) >> 13];
+                      me.cxt += (uint32_t)(wt >> 5);
+                      me.w0 = (int)((wt >> 5) ? e1 : e0);
+                      break;
+                    }
+                    default: break;
                   }
-                  default: break;
                 }
               }
+              const uint32_t mq = (desc >> 12) & 7;
+              if (mq) {                                   // a MIX: wave reduction over its input lanes
 #pragma unroll
-              for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {
-                if (q >= nmix) break;
-                if (uni(S.mix[q].level) != lv) continue;
-                const int term = (me.memb >> q & 1) ? (me.mw[q] >> 8) * me.p : 0;
-                const int sum = wave_sum(term);
-                if (lane == uni(S.mix[q].lane)) me.p = clamp2k(sum >> 8);
+                for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {
+                  if (q >= nmix) break;
+                  if (mq != 7 ? mq != q + 1 : mx_lv[q] != lv) continue;
+                  const int term = (me.memb >> q & 1) ? (me.mw[q] >> 8) * me.p : 0;
+                  const int sum = wave_sum(term);
+                  if (lane == mx_lane[q]) me.p = clamp2k(sum >> 8);
+                }
               }
             }
+            ZH_STAMP(1);
             // ================= decode the bit =================
             const uint32_t pr = rdlane((uint32_t)S.t.squash[me.p + 2048], n - 1);
             const uint32_t ps = (pr * 2 + 1) << 16;
@@ -406,16 +491,17 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
             if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane) && !err) err = bad ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF; }
             const int y = (int)(j & 1);
 
+            ZH_STAMP(2);
             // ================= update (Predictor.cs:363-461) =================
+            const int sqp = (int)S.t.squash[me.p + 2048];          // squash(p[i]) of every lane, one LDS pass
+            const int emix = (y * 32767 - sqp) * (int)me.a3 >> 4;   // MIX error term (meaningful in mixer lanes)
 #pragma unroll
             for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {      // MIX: error from the mixer lane, weights in the input lanes
               if (q >= nmix) break;
-              const uint32_t ml = uni(S.mix[q].lane), j0 = uni(S.mix[q].j0);
-              const int e = (y * 32767 - (int)S.t.squash[me.p + 2048]) * (int)me.a3 >> 4;   // valid in the mixer lane
-              const int eq = (int)rdlane((uint32_t)e, ml);
+              const int eq = (int)rdlane((uint32_t)emix, mx_lane[q]);
               if (me.memb >> q & 1) {
                 me.mw[q] = clamp512k(me.mw[q] + ((eq * me.p + (1 << 12)) >> 13));
-                S.mix[q].cm[rows[q] + (lane - j0)] = (uint32_t)me.mw[q];
+                mx_cm[q][rows[q] + (lane - mx_j0[q])] = (uint32_t)me.mw[q];
               }
             }
             switch (me.type) {
@@ -440,7 +526,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
                 break;
               }
               case ZH_ISSE: {
-                const int e = y * 32767 - (int)S.t.squash[me.p + 2048];
+                const int e = y * 32767 - sqp;
                 S.small[me.sbase + me.cxt * 2] = (uint32_t)clamp512k(me.w0 + ((e * me.pj + (1 << 12)) >> 13));
                 S.small[me.sbase + me.cxt * 2 + 1] = (uint32_t)clamp512k(me.w1 + ((e + 16) >> 5));
                 myslot[hm15] = S.t.ns[me.cxt * 4 + y];
@@ -452,7 +538,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
                 ++me.cxt;                                // finished at the byte boundary below
                 break;
               case ZH_MIX2: {
-                const int e = (y * 32767 - (int)S.t.squash[me.p + 2048]) * (int)me.a3 >> 5;
+                const int e = (y * 32767 - sqp) * (int)me.a3 >> 5;
                 int w = me.w0 + ((e * (me.pj - me.pk) + (1 << 12)) >> 13);
                 w = clampk(w, 0, 65535);
                 reinterpret_cast<uint16_t *>(me.cm)[me.cxt] = (uint16_t)w;
@@ -460,18 +546,21 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
               }
               default: break;
             }
+            ZH_STAMP(3);
             // ---- c8 / hmap4 bookkeeping (Predictor.cs:463-474)
             c8 = c8 * 2 + (uint32_t)y;
             if (c8 >= 256) break;                        // byte complete: handled below
             if (c8 >= 16 && c8 < 32) {
               hmap4 = (hmap4 & 0xf) << 5 | (uint32_t)y << 4 | 1;
               nibble_refresh();
+              ZH_STAMP(4);
             } else hmap4 = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + (uint32_t)y) & 0xf);
           }
           if (UNLIKELY(err | bad)) { status = err ? -(int)err : ZH_E_CORRUPT; break; }
           c = (int)(c8 - 256);
 
           // ---- MATCH at the byte boundary (Predictor.cs:391-410)
+          if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
           {
             const bool ism = me.type == ZH_MATCH;
             uint32_t need = 0;
@@ -489,10 +578,19 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
               } else me.a += me.a < 255;
               cm[me.h & me.cm_mask] = me.limit;
             }
+            ZH_STAMP(5);
             // h[] for the next byte: z.run(c), then H(i) (Predictor.cs:465-469)
-            const int rc = (int)uni((uint32_t)vm_run(hz, (uint32_t)c, nullptr, L.budget));
+            int rc;
+            switch (hnative) {                             // native forms of the known programs (tools/gen_zpaql_native.py)
+              case ZH_NATIVE_HCOMP_MIN: rc = zh_native_hcomp_min(ha, hb, hc, hd, hf, (uint32_t)c, S.mreg, hz.mmask, S.hreg, hmask, S.r, (Sink *)nullptr, L.budget); break;
+              case ZH_NATIVE_HCOMP_MID: rc = zh_native_hcomp_mid(ha, hb, hc, hd, hf, (uint32_t)c, S.mreg, hz.mmask, S.hreg, hmask, S.r, (Sink *)nullptr, L.budget); break;
+              case ZH_NATIVE_HCOMP_MAX: rc = zh_native_hcomp_max(ha, hb, hc, hd, hf, (uint32_t)c, S.mreg, hz.mmask, S.hreg, hmask, S.r, (Sink *)nullptr, L.budget); break;
+              default: rc = vm_run(hz, (uint32_t)c, nullptr, L.budget); break;
+            }
+            rc = (int)uni((uint32_t)rc);
             if (rc) { status = rc; break; }
             me.h = Hptr[lane & hmask];
+            ZH_STAMP(6);
             uint64_t nm = __ballot(need != 0);
             while (nm) {                                   // verify candidates with the whole wave
               const uint32_t ml = (uint32_t)__builtin_ctzll(nm);
@@ -513,6 +611,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
           }
           hmap4 = 1; c8 = 1;
           nibble_refresh();
+          ZH_STAMP(7);
         }
 
         // ---- PostProcessor.write(c) (PostProcessor.cs:37-86)
@@ -520,7 +619,11 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
         if (LIKELY(pp_state == 1)) {
           if (LIKELY(c >= 0)) out_put(ob, (uint32_t)c, lane);
         } else if (pp_state == 5) {
-          const int rc = (int)uni((uint32_t)vm_run(pz, (uint32_t)c, &sink, L.budget));
+          int rc;
+          if (pnative == ZH_NATIVE_PCOMP_E8E9)
+            rc = zh_native_pcomp_e8e9(pa, pb, pc_, pd, pf, (uint32_t)c, S.pmreg, pz.mmask, S.phreg, pz.hmask, S.pr, &sink, L.budget);
+          else rc = vm_run(pz, (uint32_t)c, &sink, L.budget);
+          rc = (int)uni((uint32_t)rc);
           if (rc) { status = rc; break; }
         } else if (pp_state == 0) {
           if (c < 0) { status = ZH_E_PP_EOS; break; }
@@ -541,6 +644,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
             __syncthreads();
             pz.prog = pzbuf; pz.len = pp_len;
             pz.a = pz.b = pz.c = pz.d = pz.f = 0;
+            pnative = p_lds ? uni(zh_native_lookup(pzbuf, pp_len)) : 0;
             pp_state = 5;
           }
         }
@@ -559,8 +663,27 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
         L.results[si] = res;
       }
     }
+    if (PROF && lane == 0 && L.debug)
+      for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
     __syncthreads();
   }
+}
+
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
+  __shared__ ChainLds S;
+  decode_chain_body<false>(L, S);
+}
+
+extern "C" __global__ __launch_bounds__(64) void zh_decode_chain_prof(ZhLaunch L) {
+  __shared__ ChainLds S;
+  decode_chain_body<true>(L, S);
+}
+
+extern "C" hipError_t zh_launch_chain_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL(zh_decode_chain_prof, dim3(grid), dim3(64), 0, stream, *L);
+  return hipGetLastError();
 }
 
 extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream) {

@@ -75,20 +75,6 @@ __device__ __forceinline__ uint32_t win_miss(uint32_t w, uint32_t &tag, uint32_t
   return slot;
 }
 
-// In-kernel stamps (diagnostic build only: zh_decode_cm_prof): cycles spent per
-// stage of a byte, summed per block and added to L.debug[stage].
-#define ZH_STAMP(i)                                                              \
-  do {                                                                           \
-    if (PROF) {                                                                  \
-      uint64_t now_;                                                             \
-      __builtin_amdgcn_sched_barrier(0);                                         \
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
-      __builtin_amdgcn_sched_barrier(0);                                         \
-      prof[i] += now_ - tprev;                                                   \
-      tprev = now_;                                                              \
-    }                                                                            \
-  } while (0)
-
 template <bool PROF>
 __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t *__restrict__ fused_g, CmLds &S) {
   uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};

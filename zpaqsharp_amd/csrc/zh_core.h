@@ -58,7 +58,13 @@ struct Vm {            // ZPAQL machine state (ZPAQL.cs:209-223)
 // ZPAQL.cs:1028-1251 execute() + :1253-1265 run0(), decoded by opcode field
 // (ISA: ZPAQL.cs:238-321).  Returns 0, ZH_E_ZPAQL or ZH_E_BUDGET.
 ZH_HD inline int vm_run(Vm &z, uint32_t input, Sink *out, uint64_t budget) {
+  // The machine description is copied to locals: `z` usually lives in LDS / memory and
+  // must not be re-read around every M/H access.
   const uint8_t *hd = z.prog;
+  uint8_t *const zm = z.m;
+  uint32_t *const zh = z.h;
+  uint32_t *const zr = z.r;
+  const uint32_t mmask = z.mmask, hmask = z.hmask, zlen = z.len;
   int pc = 0;
   uint32_t a = input, b = z.b, c = z.c, d = z.d, f = z.f;
   int rc = 0;
@@ -71,13 +77,13 @@ ZH_HD inline int vm_run(Vm &z, uint32_t input, Sink *out, uint64_t budget) {
         uint32_t n = hd[pc++];
         int off = (int)((n + 128) & 255) - 128;
         switch (ddd) {
-          case 0: a = z.r[n]; break;
-          case 1: b = z.r[n]; break;
-          case 2: c = z.r[n]; break;
-          case 3: d = z.r[n]; break;
+          case 0: a = zr[n]; break;
+          case 1: b = zr[n]; break;
+          case 2: c = zr[n]; break;
+          case 3: d = zr[n]; break;
           case 4: if (f) pc += off; break;             // JT
           case 5: if (!f) pc += off; break;            // JF
-          case 6: z.r[n] = a; break;                   // R=A
+          case 6: zr[n] = a; break;                   // R=A
           default: pc += off; break;                   // JMP
         }
         continue;
@@ -85,8 +91,8 @@ ZH_HD inline int vm_run(Vm &z, uint32_t input, Sink *out, uint64_t budget) {
       if (ddd == 7) {
         if (x == 0) break;                                                   // HALT
         if (x == 1) { if (out) sink_put(*out, a & 255); continue; }         // OUT
-        if (x == 3) { a = (a + z.m[b & z.mmask] + 512u) * 773u; continue; }  // HASH
-        if (x == 4) { uint32_t *q = &z.h[d & z.hmask]; *q = (*q + a + 512u) * 773u; continue; }  // HASHD
+        if (x == 3) { a = (a + zm[b & mmask] + 512u) * 773u; continue; }  // HASH
+        if (x == 4) { uint32_t *q = &zh[d & hmask]; *q = (*q + a + 512u) * 773u; continue; }  // HASHD
         rc = ZH_E_ZPAQL; break;
       }
       if (x > 4 || op == 0) { rc = ZH_E_ZPAQL; break; }
@@ -96,9 +102,9 @@ ZH_HD inline int vm_run(Vm &z, uint32_t input, Sink *out, uint64_t budget) {
         case 1: v = b; break;
         case 2: v = c; break;
         case 3: v = d; break;
-        case 4: v = z.m[b & z.mmask]; break;
-        case 5: v = z.m[c & z.mmask]; break;
-        default: v = z.h[d & z.hmask]; break;
+        case 4: v = zm[b & mmask]; break;
+        case 5: v = zm[c & mmask]; break;
+        default: v = zh[d & hmask]; break;
       }
       uint32_t olda = a;
       switch (x) {
@@ -116,15 +122,15 @@ ZH_HD inline int vm_run(Vm &z, uint32_t input, Sink *out, uint64_t budget) {
         case 1: b = v; break;
         case 2: c = v; break;
         case 3: d = v; break;
-        case 4: z.m[b & z.mmask] = (uint8_t)v; break;
-        case 5: z.m[c & z.mmask] = (uint8_t)v; break;
-        default: z.h[d & z.hmask] = v; break;
+        case 4: zm[b & mmask] = (uint8_t)v; break;
+        case 5: zm[c & mmask] = (uint8_t)v; break;
+        default: zh[d & hmask] = v; break;
       }
       continue;
     }
     if (op == 255) {                                   // LJ
       uint32_t t = hd[pc] + 256u * hd[pc + 1];
-      if (t >= z.len) { rc = ZH_E_ZPAQL; break; }
+      if (t >= zlen) { rc = ZH_E_ZPAQL; break; }
       pc = (int)t;
       continue;
     }
@@ -134,9 +140,9 @@ ZH_HD inline int vm_run(Vm &z, uint32_t input, Sink *out, uint64_t budget) {
       case 1: s = b; break;
       case 2: s = c; break;
       case 3: s = d; break;
-      case 4: s = z.m[b & z.mmask]; break;
-      case 5: s = z.m[c & z.mmask]; break;
-      case 6: s = z.h[d & z.hmask]; break;
+      case 4: s = zm[b & mmask]; break;
+      case 5: s = zm[c & mmask]; break;
+      case 6: s = zh[d & hmask]; break;
       default: s = hd[pc++]; break;
     }
     if (op < 128) {
@@ -145,9 +151,9 @@ ZH_HD inline int vm_run(Vm &z, uint32_t input, Sink *out, uint64_t budget) {
         case 1: b = s; break;
         case 2: c = s; break;
         case 3: d = s; break;
-        case 4: z.m[b & z.mmask] = (uint8_t)s; break;
-        case 5: z.m[c & z.mmask] = (uint8_t)s; break;
-        case 6: z.h[d & z.hmask] = s; break;
+        case 4: zm[b & mmask] = (uint8_t)s; break;
+        case 5: zm[c & mmask] = (uint8_t)s; break;
+        case 6: zh[d & hmask] = s; break;
         default: rc = ZH_E_ZPAQL; break;
       }
       if (rc) break;

@@ -164,4 +164,19 @@ __device__ __forceinline__ int dec_renorm(Dec &d, InBuf &in, uint32_t lane) {
   return (int)uni((uint32_t)rc);
 }
 
+// In-kernel stamps (diagnostic build only: *_prof kernels): cycles spent per
+// stage of a byte, summed per block and added to L.debug[stage].
+#define ZH_STAMP(i)                                                              \
+  do {                                                                           \
+    if (PROF) {                                                                  \
+      uint64_t now_;                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                         \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+      __builtin_amdgcn_sched_barrier(0);                                         \
+      prof[i] += now_ - tprev;                                                   \
+      tprev = now_;                                                              \
+    }                                                                            \
+  } while (0)
+
+
 }  // namespace zhdev
