@@ -35,6 +35,28 @@ B_ALG = {"l1": 64, "min": 128, "mid": 842, "max": 3114}
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def pmc_traffic(model, nb, bs):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/<round>/*_pmc_{FETCH,WRITE}_SIZE.csv, produced by tools/profile_bench.sh for this
+    exact workload): 2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half) + WRITE_SIZE, KB -> B.
+    None when no matching profile is committed."""
+    import csv
+    import glob
+    tag = f"{model}_{nb}x{bs >> 20}MiB"
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"*_{tag}_pmc_FETCH_SIZE.csv"))):
+        w = f.replace("FETCH_SIZE", "WRITE_SIZE")
+        if not os.path.exists(w):
+            continue
+        try:
+            fe = float(next(csv.DictReader(open(f)))["value"])
+            wr = float(next(csv.DictReader(open(w)))["value"])
+        except (StopIteration, KeyError, ValueError):
+            continue
+        best = {"bytes": (2 * fe + wr) * 1024.0, "source": os.path.relpath(f, ROOT)}
+    return best
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,7 +213,10 @@ def main():
             "kernel_kind": int(st.kernel_kind), "blocks_in_flight": int(st.concurrent),
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": (pmc_traffic(model_name, nb, bs) or {}).get("bytes"),
+                     "traffic_source": (pmc_traffic(model_name, nb, bs) or {}).get("source"),
+                     "algorithmic_bytes_per_launch": b_alg * plain_bytes,
                      "kernel_ms": kms, "alg_bytes_per_plain_byte": b_alg,
                      "note": "latency-bound bit-serial chain; see DESIGN.md §5"},
         "cpu_baseline": cpu,

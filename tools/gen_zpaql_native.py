@@ -81,7 +81,7 @@ def translate(code: bytes, name: str) -> str:
 
     out = [f"// {name}: {' '.join(zpaql.disassemble_code(code[:-1]))}",
            "template <class MP, class HP>",
-           f"ZH_HD inline int zh_native_{name}(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, uint32_t &f, uint32_t input,",
+           f"ZH_HD inline __attribute__((always_inline)) int zh_native_{name}(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, uint32_t &f, uint32_t input,",
            "    MP M, uint32_t mmask, HP H, uint32_t hmask, uint32_t *R, zhcore::Sink *out, uint64_t budget) {",
            "  a = input;", "  (void)R; (void)out; (void)budget; (void)f;"]
     for pc in starts:
@@ -156,13 +156,13 @@ def main():
         lines.append(f"#define ZH_NATIVE_{name.upper()} {i + 2}u")
     lines.append("")
     for name, code in items:
-        lines.append(f"ZH_HD inline bool zh_native_is_{name}(const uint8_t *p, uint32_t len) {{")
+        lines.append(f"ZH_HD inline __attribute__((always_inline)) bool zh_native_is_{name}(const uint8_t *p, uint32_t len) {{")
         lines.append(f"  if (len != {len(code)}u) return false;")
         chunks = [" && ".join(f"p[{i}] == {code[i]}" for i in range(k, min(k + 8, len(code)))) for k in range(0, len(code), 8)]
         lines.append("  return " + " &&\n         ".join(chunks) + ";")
         lines.append("}")
     lines.append("// Exact-match lookup (host or device).  Returns 0 when the program is not a known one.")
-    lines.append("ZH_HD inline uint32_t zh_native_lookup(const uint8_t *prog, uint32_t len) {")
+    lines.append("ZH_HD inline __attribute__((always_inline)) uint32_t zh_native_lookup(const uint8_t *prog, uint32_t len) {")
     for name, code in items:
         lines.append(f"  if (zh_native_is_{name}(prog, len)) return ZH_NATIVE_{name.upper()};")
     lines.append("  return 0;")
