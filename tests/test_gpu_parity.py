@@ -403,6 +403,9 @@ def test_kernel_selection_and_cross_kernel_agreement(ctx, model, kind):
     if model == "l1":                                           # a single CM also runs on the lane-per-component kernel
         chain = ctx.decompress(s, verify_sha1=True, kernel=3).tobytes()
         assert ctx.stats().kernel_kind == 3 and chain == data
+    else:                                                       # ... and without the model-specialised level code
+        plain = ctx.decompress(s, verify_sha1=True, kernel=4).tobytes()
+        assert ctx.stats().kernel_kind == 3 and plain == data
 
 
 def test_random_component_chains(ctx):

@@ -20,8 +20,7 @@
 
 extern "C" hipError_t zh_launch_generic(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream);
-extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
-extern "C" hipError_t zh_launch_chain_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
+extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof);
 extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream);
 
 
@@ -257,6 +256,7 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     uint32_t f = models[bd[k].model].kind & 255u;
     if (opts.kernel == 1) f = ZH_FAM_GENERIC;              // force the generic kernel
     if (opts.kernel == 3 && f == ZH_FAM_CM1) f = ZH_FAM_CHAIN;   // force the lane-per-component kernel
+    if (opts.kernel == 4 && f > ZH_FAM_CHAIN) f = ZH_FAM_CHAIN;  // lane-per-component kernel without model specialisation
     return f;
   };
   std::vector<std::vector<uint32_t>> groups(ZH_NFAM);
@@ -280,8 +280,9 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
   HIPCHK(hipMemsetAsync(c->queue.p, 0, 256, stream));
 
   // arena: sized for the most demanding group
-  uint32_t slots_of[ZH_NFAM] = {0, 0, 0};
-  uint64_t stride_of[ZH_NFAM] = {256, 256, 256}, arena_need = 0;
+  uint32_t slots_of[ZH_NFAM] = {};
+  uint64_t stride_of[ZH_NFAM], arena_need = 0;
+  for (auto &x : stride_of) x = 256;
   for (uint32_t g = 0; g < ZH_NFAM; ++g) {
     if (groups[g].empty()) continue;
     for (uint32_t k : groups[g]) stride_of[g] = std::max<uint64_t>(stride_of[g], models[bd[k].model].arena_bytes);
@@ -295,7 +296,7 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
 
   std::vector<ZhBlockDesc> bd_sorted;
   bd_sorted.reserve(sel.size());
-  size_t base_of[ZH_NFAM] = {0, 0, 0};
+  size_t base_of[ZH_NFAM] = {};
   for (uint32_t g = 0; g < ZH_NFAM; ++g) {
     // Longest block first: the work queue then balances the tail (LPT order).
     std::stable_sort(groups[g].begin(), groups[g].end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
@@ -328,12 +329,11 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     if (prof) { L.debug = (uint64_t *)c->queue.p + 16; HIPCHK(hipMemsetAsync(L.debug, 0, 64, stream)); }
     if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, (const uint16_t *)c->fused.p, slots_of[g], stream));
     else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, (const uint16_t *)c->fused.p, slots_of[g], stream));
-    else if (g == ZH_FAM_CHAIN && prof) HIPCHK(zh_launch_chain_prof(&L, slots_of[g], stream));
-    else if (g == ZH_FAM_CHAIN) HIPCHK(zh_launch_chain(&L, slots_of[g], stream));
+    else if (g >= ZH_FAM_CHAIN) HIPCHK(zh_launch_chain(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));
     else HIPCHK(zh_launch_generic(&L, slots_of[g], stream));
     ++launches;
     slots = std::max(slots, slots_of[g]);
-    kind_used = std::max(kind_used, g + 1);
+    kind_used = std::max(kind_used, std::min(g, (uint32_t)ZH_FAM_CHAIN) + 1);
   }
   HIPCHK(hipEventRecord(c->ev1, stream));
   if (getenv("ZPAQHIP_PROF")) {

@@ -28,6 +28,8 @@
 #include "zh_dev.h"
 #include "zh_model.h"
 #include "zh_zpaql_native.h"
+#define ZH_CHAIN_SPEC_DEVICE 1
+#include "zh_chain_spec.h"
 
 using namespace zhcore;
 using namespace zhdev;
@@ -59,18 +61,11 @@ static_assert(sizeof(ChainLds) <= 163840, "LDS budget");
 
 __device__ __forceinline__ int clampk(int x, int lo, int hi) { return x < lo ? lo : x > hi ? hi : x; }
 
-// Wave-wide integer sum (DPP row shifts + row broadcasts); result is wave-uniform.
-__device__ __forceinline__ int wave_sum(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
-  return (int)rdlane((uint32_t)v, 63);
-}
-
 // Per-lane view of one component (Component.cs:18-57 + its header arguments).
+struct ZhSpec_generic {                    // run-time everything (any header the host accepts for this family)
+  static constexpr uint32_t id = 0u, n = 0u, types = 0x3ffu, nmix = 0u, depth = 0u;
+};
+
 struct Lane {
   uint32_t type, a0, a1, a2, a3, a4, level;
   uint8_t *cm, *ht;                       // arena tables
@@ -111,8 +106,10 @@ __device__ __forceinline__ uint32_t find_row_lds(uint8_t *ht, uint32_t ht_mask, 
   return sel;
 }
 
-template <bool PROF>
+template <bool PROF, class SP>
 __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S) {
+  constexpr bool kSpec = SP::id != 0;
+#define ZH_HAS(t) ((SP::types >> (t)) & 1u)
   uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tprev = 0;
   const uint32_t lane = threadIdx.x;
@@ -374,44 +371,41 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             uint32_t rows[kMaxMix] = {0, 0, 0, 0};
 #pragma unroll
             for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {      // mixer rows: every input lane loads its own weight
-              if (q >= nmix) break;
+              if (q >= (kSpec ? SP::nmix : nmix)) break;
               const uint32_t rowv = ((me.h + (c8 & me.a4)) & (me.c - 1)) * mx_m[q];    // valid in the mixer lane
               rows[q] = rdlane(rowv, mx_lane[q]);
               if (me.memb >> q & 1) me.mw[q] = (int)mx_cm[q][rows[q] + (lane - mx_j0[q])];
             }
-            switch (me.type) {
-              case ZH_CM: {
-                me.cxt = (me.h ^ hmap4) & 15;
-                const uint32_t v = reinterpret_cast<const uint32_t *>(myslot)[me.cxt];
-                me.p = S.t.stretch[v >> 17];
-                break;
+            if (ZH_HAS(ZH_CM) && me.type == ZH_CM) {
+              me.cxt = (me.h ^ hmap4) & 15;
+              const uint32_t v = reinterpret_cast<const uint32_t *>(myslot)[me.cxt];
+              me.p = S.t.stretch[v >> 17];
+            }
+            if ((ZH_HAS(ZH_ICM) || ZH_HAS(ZH_ISSE)) && (me.type == ZH_ICM || me.type == ZH_ISSE)) {
+              me.cxt = myslot[hm15];                     // the bit history of this context
+              if (me.type == ZH_ICM) me.p = S.t.stretch[S.small[me.sbase + me.cxt] >> 8];
+              else {
+                const uint2 w = *reinterpret_cast<const uint2 *>(&S.small[me.sbase + me.cxt * 2]);
+                me.w0 = (int)w.x; me.w1 = (int)w.y;
               }
-              case ZH_ICM: {
-                me.cxt = myslot[hm15];
-                me.p = S.t.stretch[S.small[me.sbase + me.cxt] >> 8];
-                break;
+            }
+            if (ZH_HAS(ZH_MATCH) && me.type == ZH_MATCH) {
+              if (me.a == 0) me.p = 0;
+              else {
+                me.c = (me.mbyte >> (7 - me.cxt)) & 1;
+                me.p = S.t.stretch[(S.t.dt2k[me.a] * (1 - 2 * (int)me.c)) & 32767];
               }
-              case ZH_ISSE: {
-                me.cxt = myslot[hm15];
-                me.w0 = (int)S.small[me.sbase + me.cxt * 2];
-                me.w1 = (int)S.small[me.sbase + me.cxt * 2 + 1];
-                break;
-              }
-              case ZH_MATCH:
-                if (me.a == 0) me.p = 0;
-                else {
-                  me.c = (me.mbyte >> (7 - me.cxt)) & 1;
-                  me.p = S.t.stretch[(S.t.dt2k[me.a] * (1 - 2 * (int)me.c)) & 32767];
-                }
-                break;
-              case ZH_MIX2:
-                me.cxt = (me.h + (c8 & me.a4)) & (me.c - 1);
-                me.w0 = reinterpret_cast<const uint16_t *>(me.cm)[me.cxt];
-                break;
-              default: break;
+            }
+            if (ZH_HAS(ZH_MIX2) && me.type == ZH_MIX2) {
+              me.cxt = (me.h + (c8 & me.a4)) & (me.c - 1);
+              me.w0 = reinterpret_cast<const uint16_t *>(me.cm)[me.cxt];
             }
             ZH_STAMP(0);
             // ================= predict, dependent levels =================
+            if constexpr (SP::id == 1) zh_spec_levels_min(me, lane, c8, S.t.stretch);
+            else if constexpr (SP::id == 2) zh_spec_levels_mid(me, lane, c8, S.t.stretch);
+            else if constexpr (SP::id == 3) zh_spec_levels_max(me, lane, c8, S.t.stretch);
+            else {
             for (uint32_t lv = 1; lv <= depth; ++lv) {
               const uint32_t desc = rdlane(lvl_desc, lv & 63);
               const uint32_t one = desc & 127, typ = (desc >> 8) & 15;
@@ -475,13 +469,14 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
               if (mq) {                                   // a MIX: wave reduction over its input lanes
 #pragma unroll
                 for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {
-                  if (q >= nmix) break;
+                  if (q >= (kSpec ? SP::nmix : nmix)) break;
                   if (mq != 7 ? mq != q + 1 : mx_lv[q] != lv) continue;
                   const int term = (me.memb >> q & 1) ? (me.mw[q] >> 8) * me.p : 0;
                   const int sum = wave_sum(term);
                   if (lane == mx_lane[q]) me.p = clamp2k(sum >> 8);
                 }
               }
+            }
             }
             ZH_STAMP(1);
             // ================= decode the bit =================
@@ -497,54 +492,48 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             const int emix = (y * 32767 - sqp) * (int)me.a3 >> 4;   // MIX error term (meaningful in mixer lanes)
 #pragma unroll
             for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {      // MIX: error from the mixer lane, weights in the input lanes
-              if (q >= nmix) break;
+              if (q >= (kSpec ? SP::nmix : nmix)) break;
               const int eq = (int)rdlane((uint32_t)emix, mx_lane[q]);
               if (me.memb >> q & 1) {
                 me.mw[q] = clamp512k(me.mw[q] + ((eq * me.p + (1 << 12)) >> 13));
                 mx_cm[q][rows[q] + (lane - mx_j0[q])] = (uint32_t)me.mw[q];
               }
             }
-            switch (me.type) {
-              case ZH_CM: {
-                uint32_t *pn = &reinterpret_cast<uint32_t *>(myslot)[me.cxt];
-                const uint32_t v = *pn, cnt = v & 0x3ff;
-                const int e = y * 32767 - (int)(v >> 17);
-                *pn = v + (((uint32_t)e * (uint32_t)S.t.dt[cnt]) & 0xFFFFFC00u) + (cnt < me.limit);
-                break;
-              }
-              case ZH_SSE: {
-                const uint32_t v = (uint32_t)me.w0, cnt = v & 0x3ff;
-                const int e = y * 32767 - (int)(v >> 17);
-                reinterpret_cast<uint32_t *>(me.cm)[me.cxt & me.cm_mask] =
-                    v + (((uint32_t)e * (uint32_t)S.t.dt[cnt]) & 0xFFFFFC00u) + (cnt < me.limit);
-                break;
-              }
-              case ZH_ICM: {
-                myslot[hm15] = S.t.ns[me.cxt * 4 + y];
+            if (ZH_HAS(ZH_CM) && me.type == ZH_CM) {
+              uint32_t *pn = &reinterpret_cast<uint32_t *>(myslot)[me.cxt];
+              const uint32_t v = *pn, cnt = v & 0x3ff;
+              const int e = y * 32767 - (int)(v >> 17);
+              *pn = v + (((uint32_t)e * (uint32_t)S.t.dt[cnt]) & 0xFFFFFC00u) + (cnt < me.limit);
+            }
+            if (ZH_HAS(ZH_SSE) && me.type == ZH_SSE) {
+              const uint32_t v = (uint32_t)me.w0, cnt = v & 0x3ff;
+              const int e = y * 32767 - (int)(v >> 17);
+              reinterpret_cast<uint32_t *>(me.cm)[me.cxt & me.cm_mask] =
+                  v + (((uint32_t)e * (uint32_t)S.t.dt[cnt]) & 0xFFFFFC00u) + (cnt < me.limit);
+            }
+            if ((ZH_HAS(ZH_ICM) || ZH_HAS(ZH_ISSE)) && (me.type == ZH_ICM || me.type == ZH_ISSE)) {
+              myslot[hm15] = S.t.ns[me.cxt * 4 + y];      // next bit-history state (StateTable.next)
+              if (me.type == ZH_ICM) {
                 uint32_t *pn = &S.small[me.sbase + me.cxt];
                 *pn += (uint32_t)((int)(y * 32767 - (int)(*pn >> 8)) >> 2);
-                break;
-              }
-              case ZH_ISSE: {
+              } else {
                 const int e = y * 32767 - sqp;
-                S.small[me.sbase + me.cxt * 2] = (uint32_t)clamp512k(me.w0 + ((e * me.pj + (1 << 12)) >> 13));
-                S.small[me.sbase + me.cxt * 2 + 1] = (uint32_t)clamp512k(me.w1 + ((e + 16) >> 5));
-                myslot[hm15] = S.t.ns[me.cxt * 4 + y];
-                break;
+                uint2 w;
+                w.x = (uint32_t)clamp512k(me.w0 + ((e * me.pj + (1 << 12)) >> 13));
+                w.y = (uint32_t)clamp512k(me.w1 + ((e + 16) >> 5));
+                *reinterpret_cast<uint2 *>(&S.small[me.sbase + me.cxt * 2]) = w;
               }
-              case ZH_MATCH:
-                if ((int)me.c != y) me.a = 0;
-                me.mcur = (me.mcur * 2 + (uint32_t)y) & 255;
-                ++me.cxt;                                // finished at the byte boundary below
-                break;
-              case ZH_MIX2: {
-                const int e = (y * 32767 - sqp) * (int)me.a3 >> 5;
-                int w = me.w0 + ((e * (me.pj - me.pk) + (1 << 12)) >> 13);
-                w = clampk(w, 0, 65535);
-                reinterpret_cast<uint16_t *>(me.cm)[me.cxt] = (uint16_t)w;
-                break;
-              }
-              default: break;
+            }
+            if (ZH_HAS(ZH_MATCH) && me.type == ZH_MATCH) {
+              if ((int)me.c != y) me.a = 0;
+              me.mcur = (me.mcur * 2 + (uint32_t)y) & 255;
+              ++me.cxt;                                  // finished at the byte boundary below
+            }
+            if (ZH_HAS(ZH_MIX2) && me.type == ZH_MIX2) {
+              const int e = (y * 32767 - sqp) * (int)me.a3 >> 5;
+              int w = me.w0 + ((e * (me.pj - me.pk) + (1 << 12)) >> 13);
+              w = clampk(w, 0, 65535);
+              reinterpret_cast<uint16_t *>(me.cm)[me.cxt] = (uint16_t)w;
             }
             ZH_STAMP(3);
             // ---- c8 / hmap4 bookkeeping (Predictor.cs:463-474)
@@ -671,22 +660,26 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(64) void zh_decode_chain(ZhLaunch L) {
-  __shared__ ChainLds S;
-  decode_chain_body<false>(L, S);
-}
+#undef ZH_HAS
 
-extern "C" __global__ __launch_bounds__(64) void zh_decode_chain_prof(ZhLaunch L) {
-  __shared__ ChainLds S;
-  decode_chain_body<true>(L, S);
-}
+#define ZH_CHAIN_KERNEL(name, prof, spec)                                              \
+  extern "C" __global__ __launch_bounds__(64) void name(ZhLaunch L) {                  \
+    __shared__ ChainLds S;                                                             \
+    decode_chain_body<prof, spec>(L, S);                                               \
+  }
+ZH_CHAIN_KERNEL(zh_decode_chain, false, ZhSpec_generic)
+ZH_CHAIN_KERNEL(zh_decode_chain_min, false, ZhSpec_min)
+ZH_CHAIN_KERNEL(zh_decode_chain_mid, false, ZhSpec_mid)
+ZH_CHAIN_KERNEL(zh_decode_chain_max, false, ZhSpec_max)
+ZH_CHAIN_KERNEL(zh_decode_chain_prof, true, ZhSpec_generic)
+ZH_CHAIN_KERNEL(zh_decode_chain_mid_prof, true, ZhSpec_mid)
+ZH_CHAIN_KERNEL(zh_decode_chain_max_prof, true, ZhSpec_max)
 
-extern "C" hipError_t zh_launch_chain_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL(zh_decode_chain_prof, dim3(grid), dim3(64), 0, stream, *L);
-  return hipGetLastError();
-}
-
-extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL(zh_decode_chain, dim3(grid), dim3(64), 0, stream, *L);
+// spec: 0 generic, 1 min, 2 mid, 3 max (zh_chain_spec.h); prof: diagnostic build with stamps
+extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof) {
+  void (*k)(ZhLaunch) = zh_decode_chain;
+  if (prof) k = spec == 2 ? zh_decode_chain_mid_prof : spec == 3 ? zh_decode_chain_max_prof : zh_decode_chain_prof;
+  else k = spec == 1 ? zh_decode_chain_min : spec == 2 ? zh_decode_chain_mid : spec == 3 ? zh_decode_chain_max : zh_decode_chain;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, stream, *L);
   return hipGetLastError();
 }

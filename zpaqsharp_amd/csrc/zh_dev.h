@@ -164,6 +164,17 @@ __device__ __forceinline__ int dec_renorm(Dec &d, InBuf &in, uint32_t lane) {
   return (int)uni((uint32_t)rc);
 }
 
+// Wave-wide integer sum (DPP row shifts + row broadcasts); result is wave-uniform.
+__device__ __forceinline__ int wave_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+  return (int)rdlane((uint32_t)v, 63);
+}
+
 // In-kernel stamps (diagnostic build only: *_prof kernels): cycles spent per
 // stage of a byte, summed per block and added to L.debug[stage].
 #define ZH_STAMP(i)                                                              \

@@ -16,6 +16,7 @@
 
 #include "zh_host.h"
 #include "zh_zpaql_native.h"
+#include "zh_chain_spec.h"
 
 namespace zh {
 
@@ -378,7 +379,10 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
     m.kind = (ok && units <= 64 && nmix <= 4) ? ZH_FAM_CHAIN : ZH_FAM_GENERIC;
   }
   // ---- specialisation the kernels may use (never changes results)
-  if ((m.kind & 255u) == ZH_FAM_CHAIN) m.kind |= zh_native_lookup(hdr + cp, m.hcomp_len) << 8;   // native HCOMP id or 0
+  if ((m.kind & 255u) == ZH_FAM_CHAIN) {
+    m.kind += zh_spec_lookup(hdr, len);                                  // ZH_FAM_CHAIN + {0 none, 1 min, 2 mid, 3 max}
+    m.kind |= zh_native_lookup(hdr + cp, m.hcomp_len) << 8;              // native HCOMP id or 0
+  }
   if (m.n == 1 && m.comp[0].type == ZH_CM && m.comp[0].arg[0] >= 9) {
     m.kind = ZH_FAM_CM1;
     const uint8_t *hc = hdr + cp;                       // "a<<= K  *d=a  halt" (D is 0 at every entry)

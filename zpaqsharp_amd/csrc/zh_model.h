@@ -25,8 +25,8 @@ enum ZhCompType : uint8_t {  // LibZPAQ.cs:51-63
 
 #define ZH_FAM_GENERIC 0u        // zh_generic.hip
 #define ZH_FAM_CM1 1u            // zh_cm.hip: n == 1, one CM with >= 9 size bits
-#define ZH_FAM_CHAIN 2u          // zh_chain.hip: lane-per-component, n <= 64
-#define ZH_NFAM 3u
+#define ZH_FAM_CHAIN 2u          // zh_chain.hip: lane-per-component, n <= 64; +1/+2/+3 = specialised for min/mid/max
+#define ZH_NFAM 6u
 #define ZH_HK_GENERIC 0u         // interpret HCOMP
 #define ZH_HK_SHIFT 1u           // HCOMP == "a<<= K  *d=a  halt" with D == 0: H[0] = c << K
 
