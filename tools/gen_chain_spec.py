@@ -62,8 +62,8 @@ def gen(name, spec_id, header):
            f"  static constexpr uint32_t id = {spec_id}u, n = {n}u, types = 0x{types:x}u, nmix = {len(mixers)}u, depth = {max(lv)}u;",
            "};",
            "template <class LaneT>",
-           f"__device__ __forceinline__ void zh_spec_levels_{name}(LaneT &me, uint32_t lane, uint32_t c8, const int16_t *stretch) {{",
-           "  (void)c8; (void)stretch;"]
+           f"__device__ __forceinline__ void zh_spec_levels_{name}(LaneT &me, uint32_t lane, uint32_t c8, const int16_t *stretch, const uint8_t *arena) {{",
+           "  (void)c8; (void)stretch; (void)arena;"]
     for level in range(1, max(lv) + 1):
         out.append(f"  // level {level}")
         for i, c in enumerate(comps):
@@ -95,7 +95,7 @@ def gen(name, spec_id, header):
                 out.append("      int pq = pj + 992; pq = pq < 0 ? 0 : pq > 1983 ? 1983 : pq;")
                 out.append("      const int wt = pq & 63; pq >>= 6;")
                 out.append("      me.cxt += (uint32_t)pq;")
-                out.append("      const uint32_t *cm = reinterpret_cast<const uint32_t *>(me.cm);")
+                out.append("      const uint32_t *cm = reinterpret_cast<const uint32_t *>(arena + me.cmo);")
                 out.append("      const uint32_t e0 = cm[me.cxt & me.cm_mask], e1 = cm[(me.cxt + 1) & me.cm_mask];")
                 out.append("      me.p = stretch[((e0 >> 10) * (uint32_t)(64 - wt) + (e1 >> 10) * (uint32_t)wt) >> 13];")
                 out.append("      me.cxt += (uint32_t)(wt >> 5);")

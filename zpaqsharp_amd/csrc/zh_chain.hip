@@ -68,7 +68,8 @@ struct ZhSpec_generic {                    // run-time everything (any header th
 
 struct Lane {
   uint32_t type, a0, a1, a2, a3, a4, level;
-  uint8_t *cm, *ht;                       // arena tables
+  uint32_t cmo, hto;                      // arena offsets of the tables (the arena is < 4 GiB for this family);
+                                          // pointers are formed as slot_mem + offset so they stay GLOBAL, not flat
   uint32_t cm_mask, ht_mask;
   uint32_t sbase;                         // word offset of the ICM/ISSE table in S.small
   uint32_t limit, cxt, a, b, c;           // Component state
@@ -188,7 +189,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
       me.type = act ? cp->type : (uint32_t)ZH_NONE;
       me.a0 = cp->arg[0]; me.a1 = cp->arg[1]; me.a2 = cp->arg[2]; me.a3 = cp->arg[3]; me.a4 = cp->arg[4];
       me.level = cp->level;
-      me.cm = slot_mem + cp->cm_off; me.ht = slot_mem + cp->ht_off;
+      me.cmo = (uint32_t)cp->cm_off; me.hto = (uint32_t)cp->ht_off;
       me.cm_mask = cp->cm_mask; me.ht_mask = cp->ht_mask;
       me.sbase = (uint32_t)cp->small_unit * 256u;
       me.limit = me.cxt = me.a = me.b = me.c = 0; me.h = 0;
@@ -212,7 +213,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             S.small[me.sbase + 2 * j + 1] = (uint32_t)clamp512k(S.t.stretch[ci >> 8] * 1024);
           }
           break;
-        case ZH_MATCH: me.ht[0] = 1; break;
+        case ZH_MATCH: (slot_mem + me.hto)[0] = 1; break;
         case ZH_MIX2: case ZH_MIX: me.c = me.cm_mask + 1; break;
         case ZH_SSE: me.limit = me.a3 * 4; break;
         default: break;
@@ -231,7 +232,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
         if (!rest) break;
         const uint32_t ml = (uint32_t)__builtin_ctzll(rest);
         mx_lane[q] = ml; mx_j0[q] = rdlane(me.a1, ml); mx_m[q] = rdlane(me.a2, ml); mx_lv[q] = rdlane(me.level, ml);
-        mx_cm[q] = reinterpret_cast<uint32_t *>(uni64((uint64_t)(uintptr_t)__shfl((long long)(uintptr_t)me.cm, (int)ml)));
+        mx_cm[q] = reinterpret_cast<uint32_t *>(slot_mem + rdlane(me.cmo, ml));
         if (lane >= mx_j0[q] && lane < mx_j0[q] + mx_m[q]) me.memb |= 1u << q;
         nmix = (uint32_t)q + 1;
       }
@@ -312,22 +313,51 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
     uint32_t c8 = 1, hmap4 = 1;                        // Predictor.cs:20-21
 
     // Start of a nibble (c8 == 1 or 16 <= c8 < 32): write the old row/line back, fetch the new one.
-    auto nibble_refresh = [&]() __attribute__((always_inline)) {
+    // Split in two so that other global traffic can be put in flight between issue and use.
+    uint4 nr0 = make_uint4(0, 0, 0, 0), nr1 = nr0, nr2 = nr0, nr3 = nr0;
+    uint32_t nh0 = 0;
+    auto nibble_issue = [&]() __attribute__((always_inline)) {
       if (me.type == ZH_ICM || me.type == ZH_ISSE) {
-        if (me.rowvalid) *reinterpret_cast<uint4 *>(me.ht + me.c) = *reinterpret_cast<const uint4 *>(myslot);
-        me.c = find_row_lds(me.ht, me.ht_mask, (int)me.a0 + 2, me.h + 16u * c8, myslot);
-        me.rowvalid = true;
+        if (me.rowvalid) *reinterpret_cast<uint4 *>(slot_mem + me.hto + me.c) = *reinterpret_cast<const uint4 *>(myslot);
+        const uint32_t cxt = me.h + 16u * c8;              // Predictor.find, Predictor.cs:550-567
+        nh0 = (cxt * 16u) & (me.ht_mask - 15u);
+        nr0 = *reinterpret_cast<const uint4 *>(slot_mem + me.hto + nh0);
+        nr1 = *reinterpret_cast<const uint4 *>(slot_mem + me.hto + (nh0 ^ 16));
+        nr2 = *reinterpret_cast<const uint4 *>(slot_mem + me.hto + (nh0 ^ 32));
       } else if (me.type == ZH_CM) {
-        uint4 *g = reinterpret_cast<uint4 *>(me.cm) + (size_t)me.c * 4;
-        uint4 *l = reinterpret_cast<uint4 *>(myslot);
+        uint4 *g = reinterpret_cast<uint4 *>(slot_mem + me.cmo) + (size_t)me.c * 4;
+        const uint4 *l = reinterpret_cast<const uint4 *>(myslot);
         if (me.rowvalid) { g[0] = l[0]; g[1] = l[1]; g[2] = l[2]; g[3] = l[3]; }
         me.c = ((me.h ^ hmap4) & me.cm_mask) >> 4;     // 16-entry line of this nibble
-        g = reinterpret_cast<uint4 *>(me.cm) + (size_t)me.c * 4;
-        const uint4 x0 = g[0], x1 = g[1], x2 = g[2], x3 = g[3];
-        l[0] = x0; l[1] = x1; l[2] = x2; l[3] = x3;
+        g = reinterpret_cast<uint4 *>(slot_mem + me.cmo) + (size_t)me.c * 4;
+        nr0 = g[0]; nr1 = g[1]; nr2 = g[2]; nr3 = g[3];
+      }
+    };
+    auto nibble_finish = [&]() __attribute__((always_inline)) {
+      if (me.type == ZH_ICM || me.type == ZH_ISSE) {
+        const uint32_t chk = ((me.h + 16u * c8) >> (me.a0 + 2)) & 255;
+        uint32_t sel;
+        uint4 row;
+        if ((nr0.x & 255) == chk) { sel = nh0; row = nr0; }
+        else if ((nr1.x & 255) == chk) { sel = nh0 ^ 16; row = nr1; }
+        else if ((nr2.x & 255) == chk) { sel = nh0 ^ 32; row = nr2; }
+        else {
+          const uint32_t p0 = (nr0.x >> 8) & 255, p1 = (nr1.x >> 8) & 255, p2 = (nr2.x >> 8) & 255;
+          if (p0 <= p1 && p0 <= p2) sel = nh0;
+          else if (p1 < p2) sel = nh0 ^ 16;
+          else sel = nh0 ^ 32;
+          row = make_uint4(chk, 0, 0, 0);
+        }
+        *reinterpret_cast<uint4 *>(myslot) = row;
+        me.c = sel;
+        me.rowvalid = true;
+      } else if (me.type == ZH_CM) {
+        uint4 *l = reinterpret_cast<uint4 *>(myslot);
+        l[0] = nr0; l[1] = nr1; l[2] = nr2; l[3] = nr3;
         me.rowvalid = true;
       }
     };
+    auto nibble_refresh = [&]() __attribute__((always_inline)) { nibble_issue(); nibble_finish(); };
 
     int failed = 0;
     for (uint32_t s = 0; s < n_seg; ++s) {
@@ -398,13 +428,13 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             }
             if (ZH_HAS(ZH_MIX2) && me.type == ZH_MIX2) {
               me.cxt = (me.h + (c8 & me.a4)) & (me.c - 1);
-              me.w0 = reinterpret_cast<const uint16_t *>(me.cm)[me.cxt];
+              me.w0 = reinterpret_cast<const uint16_t *>(slot_mem + me.cmo)[me.cxt];
             }
             ZH_STAMP(0);
             // ================= predict, dependent levels =================
-            if constexpr (SP::id == 1) zh_spec_levels_min(me, lane, c8, S.t.stretch);
-            else if constexpr (SP::id == 2) zh_spec_levels_mid(me, lane, c8, S.t.stretch);
-            else if constexpr (SP::id == 3) zh_spec_levels_max(me, lane, c8, S.t.stretch);
+            if constexpr (SP::id == 1) zh_spec_levels_min(me, lane, c8, S.t.stretch, slot_mem);
+            else if constexpr (SP::id == 2) zh_spec_levels_mid(me, lane, c8, S.t.stretch, slot_mem);
+            else if constexpr (SP::id == 3) zh_spec_levels_max(me, lane, c8, S.t.stretch, slot_mem);
             else {
             for (uint32_t lv = 1; lv <= depth; ++lv) {
               const uint32_t desc = rdlane(lvl_desc, lv & 63);
@@ -432,7 +462,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
                   const int wt = pq & 63;
                   pq >>= 6;
                   me.cxt += (uint32_t)pq;
-                  const uint32_t *cm = reinterpret_cast<const uint32_t *>(me.cm);
+                  const uint32_t *cm = reinterpret_cast<const uint32_t *>(slot_mem + me.cmo);
                   const uint32_t e0 = cm[me.cxt & me.cm_mask], e1 = cm[(me.cxt + 1) & me.cm_mask];
                   me.p = S.t.stretch[((e0 >> 10) * (uint32_t)(64 - wt) + (e1 >> 10) * (uint32_t)wt) >> 13];
                   me.cxt += (uint32_t)(wt >> 5);
@@ -454,7 +484,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
                       const int wt = pq & 63;
                       pq >>= 6;
                       me.cxt += (uint32_t)pq;
-                      const uint32_t *cm = reinterpret_cast<const uint32_t *>(me.cm);
+                      const uint32_t *cm = reinterpret_cast<const uint32_t *>(slot_mem + me.cmo);
                       const uint32_t e0 = cm[me.cxt & me.cm_mask], e1 = cm[(me.cxt + 1) & me.cm_mask];
                       me.p = S.t.stretch[((e0 >> 10) * (uint32_t)(64 - wt) + (e1 >> 10) * (uint32_t)wt) >> 13];
                       me.cxt += (uint32_t)(wt >> 5);
@@ -508,7 +538,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             if (ZH_HAS(ZH_SSE) && me.type == ZH_SSE) {
               const uint32_t v = (uint32_t)me.w0, cnt = v & 0x3ff;
               const int e = y * 32767 - (int)(v >> 17);
-              reinterpret_cast<uint32_t *>(me.cm)[me.cxt & me.cm_mask] =
+              reinterpret_cast<uint32_t *>(slot_mem + me.cmo)[me.cxt & me.cm_mask] =
                   v + (((uint32_t)e * (uint32_t)S.t.dt[cnt]) & 0xFFFFFC00u) + (cnt < me.limit);
             }
             if ((ZH_HAS(ZH_ICM) || ZH_HAS(ZH_ISSE)) && (me.type == ZH_ICM || me.type == ZH_ISSE)) {
@@ -533,7 +563,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
               const int e = (y * 32767 - sqp) * (int)me.a3 >> 5;
               int w = me.w0 + ((e * (me.pj - me.pk) + (1 << 12)) >> 13);
               w = clampk(w, 0, 65535);
-              reinterpret_cast<uint16_t *>(me.cm)[me.cxt] = (uint16_t)w;
+              reinterpret_cast<uint16_t *>(slot_mem + me.cmo)[me.cxt] = (uint16_t)w;
             }
             ZH_STAMP(3);
             // ---- c8 / hmap4 bookkeeping (Predictor.cs:463-474)
@@ -555,16 +585,14 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             uint32_t need = 0;
             if (ism) {
               me.cxt = 0;
-              me.ht[me.limit & me.ht_mask] = (uint8_t)me.mcur;   // the assembled byte; ht(0)=1 is overwritten like the reference
+              (slot_mem + me.hto)[me.limit & me.ht_mask] = (uint8_t)me.mcur;   // the assembled byte; ht(0)=1 is overwritten like the reference
               me.mcur = 0;
               me.limit = (me.limit + 1) & me.ht_mask;
             }
+            uint32_t cmv = 0;
             if (ism) {                                     // still with the h[i] of the byte just coded (update0 runs before z.run)
-              uint32_t *cm = reinterpret_cast<uint32_t *>(me.cm);
-              if (me.a == 0) {
-                me.b = me.limit - cm[me.h & me.cm_mask];
-                need = (me.b & me.ht_mask) != 0;
-              } else me.a += me.a < 255;
+              uint32_t *cm = reinterpret_cast<uint32_t *>(slot_mem + me.cmo);
+              cmv = cm[me.h & me.cm_mask];                 // consumed after HCOMP: the load travels meanwhile
               cm[me.h & me.cm_mask] = me.limit;
             }
             ZH_STAMP(5);
@@ -579,13 +607,21 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             rc = (int)uni((uint32_t)rc);
             if (rc) { status = rc; break; }
             me.h = Hptr[lane & hmask];
+            hmap4 = 1; c8 = 1;
+            nibble_issue();                                // rows of the next byte's first nibble: in flight during MATCH
             ZH_STAMP(6);
+            if (ism) {
+              if (me.a == 0) {
+                me.b = me.limit - cmv;
+                need = (me.b & me.ht_mask) != 0;
+              } else me.a += me.a < 255;
+            }
             uint64_t nm = __ballot(need != 0);
             while (nm) {                                   // verify candidates with the whole wave
               const uint32_t ml = (uint32_t)__builtin_ctzll(nm);
               nm &= nm - 1;
               const uint32_t lim = rdlane(me.limit, ml), off = rdlane(me.b, ml), msk = rdlane(me.ht_mask, ml);
-              const uint8_t *hp = reinterpret_cast<const uint8_t *>(uni64((uint64_t)(uintptr_t)__shfl((long long)(uintptr_t)me.ht, (int)ml)));
+              const uint8_t *hp = slot_mem + rdlane(me.hto, ml);
               uint32_t len = 0;
               for (uint32_t base = 0; base < 256; base += 64) {
                 const uint32_t t = base + lane;
@@ -596,10 +632,10 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
               }
               if (lane == ml) me.a = len > 255 ? 255 : len;
             }
-            if (ism) me.mbyte = me.ht[(me.limit - me.b) & me.ht_mask];
+            if (ism) me.mbyte = (slot_mem + me.hto)[(me.limit - me.b) & me.ht_mask];
+            nibble_finish();
           }
-          hmap4 = 1; c8 = 1;
-          nibble_refresh();
+
           ZH_STAMP(7);
         }
 

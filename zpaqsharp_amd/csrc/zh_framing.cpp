@@ -376,7 +376,7 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
       if (c.type == ZH_CM && a[0] < 4) ok = false;       // a nibble's 16 entries must be distinct
     }
     m.depth = depth;
-    m.kind = (ok && units <= 64 && nmix <= 4) ? ZH_FAM_CHAIN : ZH_FAM_GENERIC;
+    m.kind = (ok && units <= 64 && nmix <= 4 && m.arena_bytes < (1ull << 32)) ? ZH_FAM_CHAIN : ZH_FAM_GENERIC;
   }
   // ---- specialisation the kernels may use (never changes results)
   if ((m.kind & 255u) == ZH_FAM_CHAIN) {
