@@ -27,8 +27,16 @@
 //    lane); plaintext is packed into dwords on the scalar unit, parked in a VGPR
 //    with v_writelane and leaves as one coalesced 256-byte store per 256 bytes.
 //
+//  * TWO wavefronts share the block while the PASS post-processor is active (the steady
+//    state): wave A runs nothing but the arithmetic decoder against a cache of ready-made
+//    16-bit probabilities (one per table entry of every resident window); wave B, on its own
+//    SIMD of the same CU, receives each decoded byte through an LDS ring, trains the 8
+//    entries it visited, refreshes their cached probabilities and writes the plaintext.
+//    The only true dependency — a byte whose window was touched by a byte B has not
+//    finished yet — is tracked per window and makes A wait on B's progress counter.
+//
 // Anything this kernel does not specialise (PCOMP programs, unusual HCOMP) runs
-// through the same scalar core as the generic kernel, still on the GPU.
+// through the same scalar core as the generic kernel, still on the GPU (wave A alone).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -41,19 +49,74 @@ using namespace zhdev;
 
 namespace {
 
-constexpr int kWin = 44;                  // LDS-resident CM windows
+constexpr int kWin = 36;                  // LDS-resident CM windows (2 KiB entries + 1 KiB cached probabilities each)
 constexpr uint32_t kNoWin = 0xFFFFFFFFu;
+constexpr uint32_t kRing = 16;            // A -> B message ring (entries)
+enum : uint32_t { kMsgByte = 0, kMsgMiss = 1, kMsgLeave = 2 };
+enum : uint32_t { kCmdEnter = 1, kCmdExit = 3 };
+constexpr uint32_t kSpinSection = 1u << 27;   // bounded waits: nothing may hang the GPU
+constexpr uint64_t kSpinIdle = 1ull << 33;
+#define ZH_E_HELPER (-24)                  // = ZPAQHIP_E_HIP: the helper wavefront stopped answering (cannot happen by design)
 
 struct alignas(16) CmLds {
-  uint16_t fused[32768];                  // squash(stretch(x)) * 2 + 1, x = cm >> 17
+  int16_t sh[16384];                      // stretch(x) for x in [16384, 32768); stretch(x) = -stretch(32767 - x) below
+  uint16_t sq[4096];                      // squash
   int32_t dt[1024];
-  uint32_t win[kWin][512];
+  uint32_t win[kWin][512];                // CM entries of the resident windows
+  uint16_t p16[kWin][512];                // predict()*2+1 of every entry, kept current by wave B in the steady state
+  uint32_t ring[kRing];                   // A -> B messages: tag(7) | type(2) | byte(8) | lo9(9) | slot(6)
+  uint32_t aux[kRing][2];                 // MISS: new window, victim window
+  uint32_t tags[64];                      // window directory handed to B on ENTER
+  uint32_t a_seq, b_seq;                  // messages published by A / completed by B in this section
+  uint32_t cmd_seq, cmd_code, cmd_ack;    // A -> B commands outside a section
+  uint32_t limit, ob_word, ob_room, pad0;
+  uint64_t table, ob_base, ob_cap, ob_len, ob_stored;
   uint32_t r[256];                        // HCOMP R (generic HCOMP fallback)
   uint32_t pr[256];                       // PCOMP R
   Vm hz, pz;                              // cold machine state lives here, not in registers
-  Sink sink;                              // output of a PCOMP program (lane 0 only)
+  Sink sink;                              // output of a PCOMP program
 };
 static_assert(sizeof(CmLds) <= 163840, "LDS budget");
+
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_st(uint32_t *p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// single-wave replacement of __syncthreads(): wave A must never wait on a workgroup barrier (wave B idles in a mailbox loop)
+// One dword into LDS from lane 0 only, without the compiler's exec-mask dance.  The calling wave
+// runs with all 64 lanes enabled (uniform code), so exec is restored to all ones.
+__device__ __forceinline__ void lds_put0(const uint32_t *where, uint32_t val) {
+  const uint32_t addr = (uint32_t)(uintptr_t)where;        // low half of a generic LDS pointer = LDS offset
+  asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(val) : "memory");
+}
+// The LDS unit serves one CU's requests in arrival order and a wave issues its LDS instructions
+// in program order, so "write data, then write flag" / "read flag, then read data" need no
+// s_waitcnt between them: only the compiler must not reorder.
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+// Typed LDS reads by LDS byte offset (keeps ds_read_* with folded address arithmetic).
+typedef __attribute__((address_space(3))) const uint16_t *lds_u16_p;
+typedef __attribute__((address_space(3))) const uint64_t *lds_u64_p;
+__device__ __forceinline__ uint32_t lds_u16(uint32_t off) { return *(lds_u16_p)off; }
+__device__ __forceinline__ uint64_t lds_u64(uint32_t off) { return *(lds_u64_p)off; }
+// Where the probability of window entry e (group G = e >> 4, position P = e & 15) is kept inside
+// p16[slot][]: half H = G >> 4, then quad G & 3, position, element (G >> 2) & 3 — so that a lane's
+// four second-nibble candidates (groups q, q+4, q+8, q+12 of one half, same position) are adjacent.
+__device__ __forceinline__ uint32_t p16_pos(uint32_t e) {
+  const uint32_t G = e >> 4, P = e & 15;
+  return ((G >> 4) << 8) | ((G & 3) << 6) | (P << 2) | ((G >> 2) & 3);
+}
+__device__ __forceinline__ uint32_t ring_tag(uint32_t u) { return (u >> 4) & 127u; }   // kRing == 16
+static_assert(kRing == 16, "ring_tag");
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+// predict()*2+1 for a CM entry: squash(stretch(cm >> 17)) (Predictor.cs:263-266, :349) through the half stretch table
+__device__ __forceinline__ uint32_t p16_of(const CmLds &S, uint32_t cm) {
+  const uint32_t xv = cm >> 17;
+  const int st = xv >= 16384 ? (int)S.sh[xv - 16384] : -(int)S.sh[16383 - xv];
+  return (uint32_t)S.sq[st + 2048] * 2 + 1;
+}
 
 // Window cache miss: pick the next FIFO victim, write it back, load window w.
 __device__ __forceinline__ uint32_t win_miss(uint32_t w, uint32_t &tag, uint32_t &fifo, CmLds &S, uint32_t *table,
@@ -75,21 +138,129 @@ __device__ __forceinline__ uint32_t win_miss(uint32_t w, uint32_t &tag, uint32_t
   return slot;
 }
 
+// ---------------------------------------------------------------------------------------
+// Wave B: model trainer / probability cache / plaintext writer of the steady state.
+// ---------------------------------------------------------------------------------------
+template <bool PROF>
+__device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
+  uint64_t busy = 0, tb0 = 0, tb1 = 0;
+  const uint32_t l15 = lane & 15;
+  const uint32_t ltt = 31 - __clz((int)(l15 | 1));
+  const uint32_t lsh_vis = 4 - ltt, lsh_y = 3 - ltt;
+  uint32_t seen = 0;
+  for (;;) {
+    uint64_t spin = 0;
+    uint32_t cs;
+    while ((cs = lds_ld(&S.cmd_seq)) == seen) {            // idle between sections
+      __builtin_amdgcn_s_sleep(8);
+      if (++spin > kSpinIdle) return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    seen = cs;
+    if (uni(lds_ld(&S.cmd_code)) == kCmdExit) return;
+
+    // ---- ENTER: take over the window cache and the output
+    uint32_t *table = reinterpret_cast<uint32_t *>(L.arena + uni64(S.table));   // offsets, so that accesses stay global_*
+    const uint32_t limit = uni(S.limit);
+    OutBuf ob;
+    ob.base = L.out + uni64(S.ob_base); ob.cap = uni64(S.ob_cap); ob.len = uni64(S.ob_len);
+    ob.stored = uni64(S.ob_stored); ob.word = uni(S.ob_word); ob.room = uni(S.ob_room); ob.park = 0;
+    for (uint32_t sl = 0; sl < (uint32_t)kWin; ++sl) {
+      if (uni(S.tags[sl]) == kNoWin) continue;
+      for (uint32_t i = lane; i < 512; i += 64) S.p16[sl][p16_pos(i)] = (uint16_t)p16_of(S, S.win[sl][i]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    lds_st(&S.cmd_ack, cs);
+
+    for (uint32_t u = 0;; ++u) {
+      uint32_t sp = 0, m0;
+      const uint32_t want = ring_tag(u);
+      for (;;) {                                            // next message
+        m0 = uni(lds_ld(&S.ring[u & (kRing - 1)]));
+        if (LIKELY((m0 >> 25) == want)) break;
+        if (++sp > kSpinSection) return;
+      }
+      lds_order();
+      if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0)::"memory"); }
+      const uint32_t type = (m0 >> 23) & 3, slot = m0 & 63;
+      if (LIKELY(type == kMsgByte)) {
+        const uint32_t lo9 = (m0 >> 6) & 511, c = (m0 >> 15) & 255;
+        const uint32_t g0 = lo9 >> 4, x = lo9 & 15, n1 = c >> 4, n2 = c & 15;
+        // lanes 0-15: entries of the first nibble; lanes 16-31: second nibble (group (g0^16)^n1)
+        const bool second = lane >= 16;
+        const uint32_t grp = second ? ((g0 ^ 16) ^ n1) : g0;
+        const uint32_t idx = (grp << 4) | (l15 ^ x);
+        const uint32_t nib = second ? n2 : n1;
+        const bool vis = lane < 32 && l15 != 0 && l15 == ((16 | nib) >> lsh_vis);
+        if (vis) {                                         // Predictor.train (Predictor.cs:1031-1036)
+          const uint32_t cm = S.win[slot][idx];
+          const uint32_t yy = (nib >> lsh_y) & 1, cnt = cm & 0x3ff;
+          const int err = (int)(yy * 32767) - (int)(cm >> 17);
+          const uint32_t nv = cm + (((uint32_t)err * (uint32_t)S.dt[cnt]) & 0xFFFFFC00u) + (cnt < limit);
+          S.win[slot][idx] = nv;
+          S.p16[slot][p16_pos(idx)] = (uint16_t)p16_of(S, nv);
+        }
+        lds_order();
+        lds_put0(&S.b_seq, u + 1);
+        out_put(ob, c, lane);                              // PostProcessor PASS: the byte is the plaintext
+        if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1)::"memory"); busy += tb1 - tb0; }
+        continue;
+      } else if (type == kMsgMiss) {
+        const uint32_t neww = uni(S.aux[u & (kRing - 1)][0]), oldw = uni(S.aux[u & (kRing - 1)][1]);
+        uint4 *l = reinterpret_cast<uint4 *>(&S.win[slot][0]);
+        if (oldw != kNoWin) {                              // write the victim back (coalesced, 2 x 1 KiB)
+          uint4 *g = reinterpret_cast<uint4 *>(table + (uint64_t)oldw * 512);
+          g[lane] = l[lane];
+          g[lane + 64] = l[lane + 64];
+        }
+        const uint4 *gn = reinterpret_cast<const uint4 *>(table + (uint64_t)neww * 512);
+        const uint4 a = gn[lane], b = gn[lane + 64];
+        l[lane] = a;
+        l[lane + 64] = b;
+        wave_sync();
+        for (uint32_t i = lane; i < 512; i += 64) S.p16[slot][p16_pos(i)] = (uint16_t)p16_of(S, S.win[slot][i]);
+      } else {                                             // LEAVE: hand the output state back
+        out_flush(ob, lane);
+        if (PROF && lane == 0 && L.debug) {
+          atomicAdd((unsigned long long *)&L.debug[5], (unsigned long long)busy);
+          uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+          if (((hw >> 4) & 3) == S.pad0) atomicAdd((unsigned long long *)&L.debug[7], 1ull);
+        }
+        busy = 0;
+        if (lane == 0) { S.ob_len = ob.len; S.ob_stored = ob.stored; S.ob_word = ob.word; S.ob_room = ob.room; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lds_st(&S.b_seq, u + 1);
+        break;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      lds_st(&S.b_seq, u + 1);
+    }
+  }
+}
+
 template <bool PROF>
 __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t *__restrict__ fused_g, CmLds &S) {
   uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tprev = 0;
-  const uint32_t lane = threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  (void)fused_g;
 
-  {  // model-independent tables -> LDS
-    const uint4 *src = reinterpret_cast<const uint4 *>(fused_g);
-    uint4 *dst = reinterpret_cast<uint4 *>(S.fused);
-    for (uint32_t i = lane; i < sizeof(S.fused) / 16; i += 64) dst[i] = src[i];
+  {  // model-independent tables -> LDS (both waves)
+    const uint4 *s0 = reinterpret_cast<const uint4 *>(L.tables->stretch + 16384);
+    uint4 *d0 = reinterpret_cast<uint4 *>(S.sh);
+    for (uint32_t i = threadIdx.x; i < sizeof(S.sh) / 16; i += 128) d0[i] = s0[i];
+    const uint4 *s1 = reinterpret_cast<const uint4 *>(L.tables->squash);
+    uint4 *d1 = reinterpret_cast<uint4 *>(S.sq);
+    for (uint32_t i = threadIdx.x; i < sizeof(S.sq) / 16; i += 128) d1[i] = s1[i];
     const uint4 *s2 = reinterpret_cast<const uint4 *>(L.tables->dt);
     uint4 *d2 = reinterpret_cast<uint4 *>(S.dt);
-    for (uint32_t i = lane; i < sizeof(S.dt) / 16; i += 64) d2[i] = s2[i];
+    for (uint32_t i = threadIdx.x; i < sizeof(S.dt) / 16; i += 128) d2[i] = s2[i];
+    if (threadIdx.x == 0) { S.cmd_seq = 0; S.cmd_code = 0; S.cmd_ack = 0; S.a_seq = 0; S.b_seq = 0; }
   }
-  __syncthreads();
+  __syncthreads();                                       // the only workgroup barrier of the kernel
+  if (wave == 1) { helper_wave<PROF>(L, S, lane); return; }
+  if (PROF) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); if (lane == 0) S.pad0 = (hw >> 4) & 3; }
+  uint32_t cmd_seq = 0;                                  // commands issued to wave B so far
 
   // per-lane constants of the lane <-> table-entry mapping
   const uint32_t l15 = lane & 15;                      // nibble context j held by this lane
@@ -128,7 +299,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
       for (uint64_t i = lane; i < tail / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
       for (uint32_t i = lane; i < 256; i += 64) { S.r[i] = 0; S.pr[i] = 0; }
     }
-    __syncthreads();
+    wave_sync();
 
     uint32_t tag = kNoWin;                             // per-lane window directory (lanes >= kWin never match)
     uint32_t fifo = 0;
@@ -161,7 +332,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
     Sink &sink = S.sink;                               // used only when a PCOMP program emits output
     sink.out = ob.base; sink.cap = ob.cap; sink.len = 0;
 
-    __syncthreads();
+    wave_sync();
     InBuf in;
     in.stream = L.in; in.total = L.in_total; in.cbase = 0; in.k = 0; in.avail = 0; in.cur = 0;
 
@@ -220,9 +391,9 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
           uint32_t cmb[4], pb[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) cmb[k] = win[ib0 + 64 * k];
-          const uint32_t pa = (uint32_t)S.fused[cma >> 17] << 16;
+          const uint32_t pa = p16_of(S, cma) << 16;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) pb[k] = (uint32_t)S.fused[cmb[k] >> 17] << 16;
+          for (int k = 0; k < 4; ++k) pb[k] = p16_of(S, cmb[k]) << 16;
           ZH_STAMP(2);
 
           // ---- first nibble: context j lives in lane j
@@ -285,30 +456,171 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
       };
 
       for (;;) {
-        if (LIKELY(pp_state == 1)) {
-          // ---- steady state: PASS post-processor (PostProcessor.cs:49-51).  Nothing of the cold
-          // state machine below is live in this loop.
-          // Entering the steady-state loop: pin every loop-carried scalar to the scalar unit, so
-          // that LLVM's uniformity analysis sees a loop whose state is uniform on entry and on the
-          // back edge (a value it believes divergent anywhere outside would otherwise drag the
-          // whole loop onto the vector unit with exec-mask control flow).
+        if (LIKELY(pp_state == 1 && hk == ZH_HK_SHIFT)) {
+          // ---- steady state: PASS post-processor (PostProcessor.cs:49-51) and the recognised HCOMP.
+          // ===== two-wave steady state =====
+          // hand the window cache and the output to wave B
+          S.tags[lane] = tag;
+          if (lane < kRing) S.ring[lane] = 0xFFFFFFFFu;   // tag 127: never the tag of messages 0..15
+          out_flush(ob, lane);
+          if (lane == 0) {
+            S.table = (uint64_t)(reinterpret_cast<uint8_t *>(table) - L.arena); S.limit = limit;
+            S.ob_base = (uint64_t)(ob.base - L.out); S.ob_cap = ob.cap; S.ob_len = ob.len; S.ob_stored = ob.stored;
+            S.ob_word = ob.word; S.ob_room = ob.room;
+            S.a_seq = 0; S.b_seq = 0; S.cmd_code = kCmdEnter;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          ++cmd_seq;
+          lds_st(&S.cmd_seq, cmd_seq);
+          bool helper_ok = true;
+          {
+            uint32_t sp = 0;
+            while (lds_ld(&S.cmd_ack) != cmd_seq) { if (++sp > kSpinSection) { helper_ok = false; break; } }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          }
+          if (!helper_ok) { status = ZH_E_HELPER; break; }
+          // Pin every loop-carried scalar to the scalar unit, so that LLVM's uniformity analysis sees a
+          // loop whose state is uniform on entry and on the back edge.
           d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr);
           in.cbase = uni64(in.cbase); in.k = uni(in.k); in.avail = uni(in.avail);
-          ob.len = uni64(ob.len); ob.stored = uni64(ob.stored); ob.room = uni(ob.room); ob.word = uni(ob.word);
           h0 = uni(h0); fifo = uni(fifo);
-          int c;
+          uint32_t t = 0, b_done = 0;                     // messages published / known completed
+          uint32_t lastuse = 0;                           // lane s: message count after the last one touching window slot s
+          auto publish = [&](uint32_t m0) __attribute__((always_inline)) {
+            lds_order();
+            lds_put0(&S.ring[t & (kRing - 1)], ring_tag(t) << 25 | m0);
+            ++t;
+          };
+          auto wait_done = [&](uint32_t upto) __attribute__((always_inline)) -> bool {   // until b_seq >= upto
+            uint32_t sp = 0;
+            while ((int32_t)(b_done - upto) < 0) {
+              b_done = uni(lds_ld(&S.b_seq));
+              if (++sp > kSpinSection) return false;
+            }
+            lds_order();
+            return true;
+          };
+          // The loop has ONE exit (the EOS test): an error lets the byte run to its end on whatever
+          // state it has, commits nothing, and forces that test; the common path carries no exit bookkeeping.
+          enum : uint32_t { kEvEos = 1, kEvCorrupt, kEvEof, kEvHelper };
+          uint32_t ev = 0;
+          const uint32_t p16_base = (uint32_t)(uintptr_t)&S.p16[0][0];
+          const uint32_t lane_b = p16_base + lgrp * 128;  // second-nibble quad of this lane inside a half window
+          uint32_t tq;
           for (;;) {
-            c = (int)uni((uint32_t)decode_byte());
-            if (UNLIKELY(c < 0)) break;
-            out_put(ob, (uint32_t)c, lane);
+            if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
+            // ---- Decoder.decompress prologue (Decoder.cs:36-45)
+            if (UNLIKELY(d.curr == 0)) {
+              uint32_t cu = 0;
+              for (int i = 0; i < 4; ++i) cu = cu << 8 | (uint32_t)in_get(in, lane);
+              d.curr = uni(cu);
+            }
+            // ---- EOS flag, p = 0 (Decoder.cs:136-158 with mid = low): y = (curr <= low)
+            tq = d.curr - d.low;
+            if (UNLIKELY(tq - 1 >= d.high - d.low)) break;   // tq == 0: y = 1;  tq > high - low: "archive corrupted"
+            uint32_t bad = 0, err = 0, helper_lost = 0;
+            d.low += 1;
+            if (UNLIKELY((d.high ^ d.low) < 0x1000000u)) {
+              if (dec_renorm_chk(d, in, lane, bad)) err = kEvEof;
+            }
+            ZH_STAMP(0);
+            const uint32_t hm = h0 & cm_mask;
+            const uint32_t w = hm >> 9, lo9 = hm & 511, g0 = lo9 >> 4, x = lo9 & 15;
+            const uint64_t hit = __ballot(tag == w);
+            uint32_t slot;
+            if (LIKELY(hit != 0)) slot = (uint32_t)__builtin_ctzll(hit);
+            else {                                        // window miss: wave B swaps the window
+              slot = fifo;
+              fifo = fifo + 1 == (uint32_t)kWin ? 0 : fifo + 1;
+              const uint32_t old = rdlane(tag, slot);
+              tag = lane == slot ? w : tag;
+              if (lane == 0) { uint32_t *q = S.aux[t & (kRing - 1)]; q[0] = w; q[1] = old; }
+              publish(kMsgMiss << 23 | slot);
+              lastuse = lane == slot ? t : lastuse;
+            }
+            // The cached probabilities of this window must include every earlier byte that used it, and
+            // the ring must not overrun: B may be at most `back` messages behind.
+            {
+              const uint32_t since = t - rdlane(lastuse, slot);
+              const uint32_t back = since < kRing - 3 ? since : kRing - 3;
+              if (UNLIKELY(t - b_done > back)) { if (!wait_done(t - back)) helper_lost = 1; }
+            }
+            ZH_STAMP(1);
+            // p16 storage order inside a window (p16_pos): the four second-nibble entries a lane needs
+            // are one 8-byte read, the first-nibble entry one 2-byte read.
+            const uint32_t pos8 = (l15 ^ x) << 3;
+            const uint32_t s_win = slot << 10;
+            const uint32_t s_a = s_win + ((g0 >> 4) << 9) + ((g0 & 3) << 7) + (((g0 >> 2) & 3) << 1);
+            const uint32_t s_b = s_win + (((g0 >> 4) ^ 1) << 9);
+            const uint32_t pa = (uint32_t)lds_u16(p16_base + s_a + pos8) << 16;
+            const uint64_t pb = lds_u64(lane_b + s_b + pos8);
+            ZH_STAMP(2);
+            uint32_t j = 1;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+              const uint32_t ps = rdlane(pa, j);
+              uint32_t xr;
+              ZH_DEC_STEP_LITE(d, ps, j, xr);
+              if (UNLIKELY(xr < 0x1000000u)) {
+                const uint32_t was = bad;
+                if (dec_renorm_chk(d, in, lane, bad) && !err) err = was ? kEvCorrupt : kEvEof;
+              }
+            }
+            ZH_STAMP(3);
+            // second nibble: group (g0 ^ n1) & 15 of the other half = quad (ga & 3), element ga >> 2
+            const uint32_t ga = uni((g0 ^ j) & 15), lb = (ga & 3) * 16;
+            const uint32_t psel = (uint32_t)(pb >> ((ga >> 2) * 16)) << 16;
+            uint32_t j2 = 1;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+              const uint32_t ps = rdlane(psel, lb + j2);
+              uint32_t xr;
+              ZH_DEC_STEP_LITE(d, ps, j2, xr);
+              if (UNLIKELY(xr < 0x1000000u)) {
+                // after the byte's last bit the next call re-primes / re-checks by itself (Decoder.cs:36-45)
+                uint32_t later = 0;
+                const uint32_t was = bad;
+                if (dec_renorm_chk(d, in, lane, tt == 3 ? later : bad) && !err) err = was ? kEvCorrupt : kEvEof;
+              }
+            }
+            ZH_STAMP(4);
+            if (LIKELY((err | bad | helper_lost) == 0)) {
+              const uint32_t cc = (j << 4) + j2 - 272;     // j = 16 | n1, j2 = 16 | n2
+              // the byte goes to wave B: training, probability refresh and output happen there
+              publish(kMsgByte << 23 | cc << 15 | lo9 << 6 | slot);
+              lastuse = lane == slot ? t : lastuse;
+              h0 = cc << hshift;                           // HCOMP "a<<= K  *d=a  halt" (Predictor.cs:464-470)
+            } else {
+              // an error ends the section through the loop's only exit: make the next EOS test fire
+              ev = helper_lost ? (uint32_t)kEvHelper : err ? err : (uint32_t)kEvCorrupt;
+              d.low = d.high = d.curr = 1;
+            }
             ZH_STAMP(6);
           }
+          if (!ev) ev = tq ? kEvCorrupt : kEvEos;
+          int c = -2;
+          if (ev == kEvEos) {                             // y = 1: high = mid = low, then the usual renormalisation
+            d.high = d.low;
+            if (dec_renorm(d, in, lane)) status = ZH_E_EOF;
+            else if (d.curr != 0) status = ZH_E_EOS;
+            else c = -1;
+          } else {
+            status = ev == kEvCorrupt ? ZH_E_CORRUPT : ev == kEvEof ? ZH_E_EOF : ZH_E_HELPER;
+          }
+          (void)c;
+          // leave the section: B flushes the output and hands its state back
+          publish(kMsgLeave << 23);
+          if (!wait_done(t) && !status) status = ZH_E_HELPER;
+          ob.len = uni64(S.ob_len); ob.stored = uni64(S.ob_stored); ob.word = uni(S.ob_word); ob.room = uni(S.ob_room);
+          ob.park = 0;
           break;                                          // EOS (c == -1) or error (c == -2)
         }
         int c = decode_byte();
         if (c == -2) break;
         // ---- PostProcessor.write(c) (PostProcessor.cs:37-86)
-        if (pp_state == 5) {
+        if (pp_state == 1) {
+          if (c >= 0) out_put(ob, (uint32_t)c, lane);
+        } else if (pp_state == 5) {
           // every lane runs the program (same inputs, same stores): keeps control flow wave-uniform
           int rc = (int)uni((uint32_t)vm_run(pz, (uint32_t)c, &sink, L.budget));
           if (rc) { status = rc; break; }
@@ -328,7 +640,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
           if (c < 0) { status = ZH_E_PP_EOS; break; }
           pzbuf[pp_len] = (uint8_t)c;                  // all lanes store the same byte
           if ((int)++pp_len == pp_hsize) {
-            __syncthreads();
+            wave_sync();
             pz.prog = pzbuf; pz.len = pp_len;
             pz.a = pz.b = pz.c = pz.d = pz.f = 0;
             pp_state = 5;
@@ -350,29 +662,32 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
       }
     }
     if (PROF && lane == 0 && L.debug)
-      for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
-    __syncthreads();
+      for (int i = 0; i < 8; ++i) if (i != 5 && i != 7) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
+    wave_sync();
   }
+  if (lane == 0) S.cmd_code = kCmdExit;                  // release wave B
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  lds_st(&S.cmd_seq, cmd_seq + 1);
 }
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(64) void zh_decode_cm(ZhLaunch L, const uint16_t *__restrict__ fused_g) {
+extern "C" __global__ __launch_bounds__(128) void zh_decode_cm(ZhLaunch L, const uint16_t *__restrict__ fused_g) {
   __shared__ CmLds S;
   decode_cm_body<false>(L, fused_g, S);
 }
 
-extern "C" __global__ __launch_bounds__(64) void zh_decode_cm_prof(ZhLaunch L, const uint16_t *__restrict__ fused_g) {
+extern "C" __global__ __launch_bounds__(128) void zh_decode_cm_prof(ZhLaunch L, const uint16_t *__restrict__ fused_g) {
   __shared__ CmLds S;
   decode_cm_body<true>(L, fused_g, S);
 }
 
 extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL(zh_decode_cm_prof, dim3(grid), dim3(64), 0, stream, *L, fused);
+  hipLaunchKernelGGL(zh_decode_cm_prof, dim3(grid), dim3(128), 0, stream, *L, fused);
   return hipGetLastError();
 }
 
 extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL(zh_decode_cm, dim3(grid), dim3(64), 0, stream, *L, fused);
+  hipLaunchKernelGGL(zh_decode_cm, dim3(grid), dim3(128), 0, stream, *L, fused);
   return hipGetLastError();
 }

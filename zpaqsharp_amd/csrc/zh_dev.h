@@ -147,6 +147,30 @@ struct Dec { uint32_t low, high, curr; };
         : "scc");                                                                                   \
   } while (0)
 
+// The same step without the range check and with the renormalisation test left to the caller
+// (x = high ^ low after the split; renormalise when x < 2^24).  The check may be dropped because
+// the split keeps low <= curr <= high: only priming and the `low += (low == 0)` of a
+// renormalisation can break the invariant, and dec_renorm_chk reports exactly that.
+#define ZH_DEC_STEP_LITE(d, ps, j, x)                                                               \
+  do {                                                                                              \
+    uint32_t r_, t_, off_, mid_, m1_;                                                               \
+    asm volatile(                                                                                   \
+        "s_sub_u32 %[r], %[high], %[low]\n\t"                                                       \
+        "s_sub_u32 %[t], %[curr], %[low]\n\t"                                                       \
+        "s_mul_hi_u32 %[off], %[r], %[p]\n\t"                                                       \
+        "s_add_u32 %[mid], %[low], %[off]\n\t"                                                      \
+        "s_add_u32 %[m1], %[mid], 1\n\t"                                                            \
+        "s_cmp_le_u32 %[t], %[off]\n\t"                                                             \
+        "s_cselect_b32 %[high], %[mid], %[high]\n\t"                                                \
+        "s_cselect_b32 %[low], %[low], %[m1]\n\t"                                                   \
+        "s_addc_u32 %[jj], %[jj], %[jj]\n\t"                                                        \
+        "s_xor_b32 %[xx], %[high], %[low]"                                                          \
+        : [low] "+s"(d.low), [high] "+s"(d.high), [curr] "+s"(d.curr), [jj] "+s"(j), [xx] "=s"(x),  \
+          [r] "=&s"(r_), [t] "=&s"(t_), [off] "=&s"(off_), [mid] "=&s"(mid_), [m1] "=&s"(m1_)       \
+        : [p] "s"(ps)                                                                               \
+        : "scc");                                                                                   \
+  } while (0)
+
 // Renormalisation loop of Decoder.decode (Decoder.cs:148-156).  Returns 0 or ZH_E_EOF.
 __device__ __forceinline__ int dec_renorm(Dec &d, InBuf &in, uint32_t lane) {
   int rc = 0;
@@ -162,6 +186,14 @@ __device__ __forceinline__ int dec_renorm(Dec &d, InBuf &in, uint32_t lane) {
   // this rare path may be selected onto the vector unit; hand the state back as scalars
   d.low = uni(low); d.high = uni(high); d.curr = uni(curr);
   return (int)uni((uint32_t)rc);
+}
+
+// dec_renorm plus the range test the NEXT Decoder.decode call would make (Decoder.cs:138):
+// `bad` is raised when the renormalised state has curr outside [low, high].  Not touched on EOF.
+__device__ __forceinline__ int dec_renorm_chk(Dec &d, InBuf &in, uint32_t lane, uint32_t &bad) {
+  const int rc = dec_renorm(d, in, lane);
+  if (!rc) bad = uni(bad | (uint32_t)(d.curr < d.low) | (uint32_t)(d.curr > d.high));
+  return rc;
 }
 
 // Wave-wide integer sum (DPP row shifts + row broadcasts); result is wave-uniform.
