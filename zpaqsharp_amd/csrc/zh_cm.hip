@@ -42,6 +42,7 @@
 
 #include "zh_core.h"
 #include "zh_dev.h"
+#include "zh_cm_fast.h"
 #include "zh_model.h"
 
 using namespace zhcore;
@@ -507,7 +508,21 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
           const uint32_t p16_base = (uint32_t)(uintptr_t)&S.p16[0][0];
           const uint32_t lane_b = p16_base + lgrp * 128;  // second-nibble quad of this lane inside a half window
           uint32_t tq;
+          // hand-written loop for the common case (zh_cm_fast.h); the C++ body below is the same
+          // algorithm and takes every byte the fast loop declines
+          const bool fast_ok = !PROF && hshift >= 9 && hshift < 32;
+          const uint32_t fast_la = p16_base + (l15 << 3), fast_lb = p16_base + 512 + lgrp * 128 + (l15 << 3);
+          const uint32_t fast_ring = (uint32_t)(uintptr_t)&S.ring[0], fast_bsa = (uint32_t)(uintptr_t)&S.b_seq;
           for (;;) {
+            if (fast_ok) {
+              if (in.avail - in.k < 40 && in.avail == 256) in_seek(in, in_pos(in), lane);   // re-centre the chunk
+              uint32_t code;
+              d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr); in.k = uni(in.k); in.avail = uni(in.avail);
+              t = uni(t); h0 = uni(h0); b_done = uni(b_done);
+              ZH_CM_FAST_LOOP(d.low, d.high, d.curr, in.k, t, h0, b_done, lastuse, code, in.avail, uni(cm_mask), uni(hshift),
+                              uni(fast_ring), fast_bsa, in.cur, tag, lane, fast_la, fast_lb);
+              if (UNLIKELY(code)) { ev = kEvCorrupt; d.low = d.high = d.curr = 1; }   // the EOS test below ends the section
+            }
             if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
             // ---- Decoder.decompress prologue (Decoder.cs:36-45)
             if (UNLIKELY(d.curr == 0)) {

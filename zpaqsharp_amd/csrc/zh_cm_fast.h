@@ -1,0 +1,193 @@
+// zh_cm_fast.h — the steady-state byte loop of wave A (zh_cm.hip) written directly in gfx950 assembly.
+//
+// One iteration = one byte of Decoder.decompress (Decoder.cs:32-56) for a block whose model is a
+// single direct CM and whose HCOMP is "a<<= K  *d=a  halt" with K >= 9 (so the low 9 bits of the
+// context hash are zero: first-nibble group 0, second-nibble groups 16..31 of the window).
+//
+// The loop only runs when nothing unusual can happen inside the byte.  It checks, before it
+// changes any state, that
+//   * the coder is primed (curr != 0) and at least 40 coded bytes are in the register-held chunk
+//     (a byte consumes at most 9 x 4), so a renormalisation never has to refill or can hit EOF;
+//   * the context's window is resident (otherwise wave B must swap it in);
+//   * wave B has finished every earlier byte that touched that window and the ring has room;
+//   * the EOS flag decodes as 0 and the state is in range (Decoder.cs:138).
+// If any test fails it leaves with code 0 and the C++ body of the loop in zh_cm.hip handles that
+// byte (it is the same algorithm, including the rare cases), then re-enters.  Code 1 = the range
+// check after a renormalisation failed ("archive corrupted").
+//
+// Per decoded bit: v_readlane (probability of tree node j), 10 SALU instructions for the split
+// (Decoder.cs:140-147; mulhi against p16 << 16 replaces the 64-bit multiply and shift), and a
+// compare + branch for the renormalisation, which is out of line.
+//
+// Register use: operands are allocated by the compiler; temporaries are the fixed registers
+// s80-s94 and v250-v252 (declared as clobbers).  exec is all ones on entry and exit.
+#pragma once
+
+// clang-format off
+#define ZH_FAST_STEP(PV, J, IDX, N)                                   \
+  "v_readlane_b32 s94, " PV ", " IDX "\n\t"                           \
+  "s_sub_u32 s84, %[high], %[low]\n\t"                                \
+  "s_sub_u32 s85, %[curr], %[low]\n\t"                                \
+  "s_mul_hi_u32 s86, s84, s94\n\t"                                    \
+  "s_add_u32 s87, %[low], s86\n\t"                                    \
+  "s_add_u32 s88, s87, 1\n\t"                                         \
+  "s_cmp_le_u32 s85, s86\n\t"                                         \
+  "s_cselect_b32 %[high], s87, %[high]\n\t"                           \
+  "s_cselect_b32 %[low], %[low], s88\n\t"                             \
+  "s_addc_u32 " J ", " J ", " J "\n\t"                                \
+  "s_xor_b32 s84, %[high], %[low]\n\t"                                \
+  "s_cmp_lt_u32 s84, 0x1000000\n\t"                                   \
+  "s_cbranch_scc1 .Lzh_rn" #N "_%=\n"                                 \
+  ".Lzh_bk" #N "_%=:\n\t"
+
+// Renormalisation (Decoder.cs:148-156): shift a coded byte in while the top bytes of low and
+// high agree; then the range test the next decode() would make (skipped after the byte's last
+// bit, where the next call re-primes and re-checks by itself).
+#define ZH_FAST_RENORM(N, CHK)                                        \
+  ".Lzh_rn" #N "_%=:\n\t"                                             \
+  "s_lshl_b32 %[high], %[high], 8\n\t"                                \
+  "s_or_b32 %[high], %[high], 0xff\n\t"                               \
+  "s_lshl_b32 %[low], %[low], 8\n\t"                                  \
+  "s_max_u32 %[low], %[low], 1\n\t"                                   \
+  "s_lshr_b32 s84, %[k], 2\n\t"                                       \
+  "v_readlane_b32 s85, %[cur], s84\n\t"                               \
+  "s_lshl_b32 s84, %[k], 3\n\t"                                       \
+  "s_lshr_b32 s85, s85, s84\n\t"                                      \
+  "s_and_b32 s85, s85, 0xff\n\t"                                      \
+  "s_lshl_b32 %[curr], %[curr], 8\n\t"                                \
+  "s_or_b32 %[curr], %[curr], s85\n\t"                                \
+  "s_add_u32 %[k], %[k], 1\n\t"                                       \
+  "s_xor_b32 s84, %[high], %[low]\n\t"                                \
+  "s_cmp_lt_u32 s84, 0x1000000\n\t"                                   \
+  "s_cbranch_scc1 .Lzh_rn" #N "_%=\n\t"                               \
+  CHK                                                                 \
+  "s_branch .Lzh_bk" #N "_%=\n\t"
+
+#define ZH_FAST_CHK                                                   \
+  "s_cmp_lt_u32 %[curr], %[low]\n\t"                                  \
+  "s_cselect_b32 s93, 1, s93\n\t"                                     \
+  "s_cmp_gt_u32 %[curr], %[high]\n\t"                                 \
+  "s_cselect_b32 s93, 1, s93\n\t"
+
+// s80 scratch   s81 window id   s82 slot   s83 back   s84-s88 step scratch   s89 lag
+// s90 j (16|n1) s91 j2 (16|n2)  s92 byte   s93 bad    s94 probability
+// v250:v251 four second-nibble probabilities / selected one   v252 first-nibble probabilities, scratch
+#define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, avail_, mask_, hs_, ring_, bsa_, cur_, tag_, lid_, la_, lb_) \
+  asm volatile(                                                       \
+  ".Lzh_byte_%=:\n\t"                                                 \
+  "s_cmp_eq_u32 %[curr], 0\n\t"                                       \
+  "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
+  "s_sub_u32 s80, %[avail], %[k]\n\t"                                 \
+  "s_cmp_lt_u32 s80, 40\n\t"                                          \
+  "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
+  /* window lookup: lane s of `tag` holds the window id cached in slot s */ \
+  "s_and_b32 s81, %[h0], %[mask]\n\t"                                 \
+  "s_lshr_b32 s81, s81, 9\n\t"                                        \
+  "v_cmp_eq_u32_e32 vcc, s81, %[tag]\n\t"                             \
+  "s_cbranch_vccz .Lzh_slow_%=\n\t"                                   \
+  "s_ff1_i32_b64 s82, vcc\n\t"                                        \
+  /* wave B may be at most min(messages since the window's last use, 13) behind */ \
+  "v_readlane_b32 s83, %[lu], s82\n\t"                                \
+  "s_sub_u32 s83, %[t], s83\n\t"                                      \
+  "s_min_u32 s83, s83, 13\n\t"                                        \
+  "s_sub_u32 s89, %[t], %[bdone]\n\t"                                 \
+  "s_cmp_gt_u32 s89, s83\n\t"                                         \
+  "s_cbranch_scc1 .Lzh_fresh_%=\n"                                    \
+  ".Lzh_ok_%=:\n\t"                                                   \
+  /* EOS flag (p = 0): y = curr <= low; leave when y = 1 or curr is out of range */ \
+  "s_sub_u32 s80, %[curr], %[low]\n\t"                                \
+  "s_sub_u32 s84, %[high], %[low]\n\t"                                \
+  "s_add_u32 s80, s80, -1\n\t"                                        \
+  "s_cmp_ge_u32 s80, s84\n\t"                                         \
+  "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
+  "s_add_u32 %[low], %[low], 1\n\t"                                   \
+  /* cached probabilities: lane j <- node j of the first nibble; lane (q, j) <- node j of groups q, q+4, q+8, q+12 */ \
+  "s_lshl_b32 s80, s82, 10\n\t"                                       \
+  "v_add_u32_e32 v252, s80, %[la]\n\t"                                \
+  "v_add_u32_e32 v250, s80, %[lb]\n\t"                                \
+  "ds_read_u16 v252, v252\n\t"                                        \
+  "ds_read_b64 v[250:251], v250\n\t"                                  \
+  "s_mov_b32 s93, 0\n\t"                                              \
+  "s_mov_b32 s90, 1\n\t"                                              \
+  "s_xor_b32 s84, %[high], %[low]\n\t"                                \
+  "s_cmp_lt_u32 s84, 0x1000000\n\t"                                   \
+  "s_cbranch_scc1 .Lzh_rn0_%=\n"                                      \
+  ".Lzh_bk0_%=:\n\t"                                                  \
+  "s_waitcnt lgkmcnt(1)\n\t"                                          \
+  "v_lshlrev_b32_e32 v252, 16, v252\n\t"                              \
+  ZH_FAST_STEP("v252", "s90", "s90", 1)                               \
+  ZH_FAST_STEP("v252", "s90", "s90", 2)                               \
+  ZH_FAST_STEP("v252", "s90", "s90", 3)                               \
+  ZH_FAST_STEP("v252", "s90", "s90", 4)                               \
+  /* second nibble: group n1 = quad (n1 & 3), element n1 >> 2 */      \
+  "s_lshl_b32 s80, s90, 2\n\t"                                        \
+  "s_and_b32 s80, s80, 48\n\t"                                        \
+  "s_and_b32 s89, s90, 3\n\t"                                         \
+  "s_lshl_b32 s89, s89, 4\n\t"                                        \
+  "s_waitcnt lgkmcnt(0)\n\t"                                          \
+  "v_lshrrev_b64 v[250:251], s80, v[250:251]\n\t"                     \
+  "v_lshlrev_b32_e32 v250, 16, v250\n\t"                              \
+  "s_mov_b32 s91, 1\n\t"                                              \
+  "s_add_u32 s80, s89, s91\n\t"                                       \
+  ZH_FAST_STEP("v250", "s91", "s80", 5)                               \
+  "s_add_u32 s80, s89, s91\n\t"                                       \
+  ZH_FAST_STEP("v250", "s91", "s80", 6)                               \
+  "s_add_u32 s80, s89, s91\n\t"                                       \
+  ZH_FAST_STEP("v250", "s91", "s80", 7)                               \
+  "s_add_u32 s80, s89, s91\n\t"                                       \
+  ZH_FAST_STEP("v250", "s91", "s80", 8)                               \
+  "s_cmp_lg_u32 s93, 0\n\t"                                           \
+  "s_cbranch_scc1 .Lzh_corrupt_%=\n\t"                                \
+  /* byte = (j << 4) + j2 - 272;  message to wave B: tag(t) << 25 | byte << 15 | slot */ \
+  "s_lshl4_add_u32 s92, s90, s91\n\t"                                 \
+  "s_add_u32 s92, s92, 0xfffffef0\n\t"                                \
+  "s_lshl_b32 s80, %[t], 21\n\t"                                      \
+  "s_and_b32 s80, s80, 0xfe000000\n\t"                                \
+  "s_lshl_b32 s84, s92, 15\n\t"                                       \
+  "s_or_b32 s80, s80, s84\n\t"                                        \
+  "s_or_b32 s80, s80, s82\n\t"                                        \
+  "s_and_b32 s84, %[t], 15\n\t"                                       \
+  "s_lshl_b32 s84, s84, 2\n\t"                                        \
+  "s_add_u32 s84, s84, %[ring]\n\t"                                   \
+  "v_mov_b32_e32 v252, s84\n\t"                                       \
+  "v_mov_b32_e32 v250, s80\n\t"                                       \
+  "s_mov_b64 exec, 1\n\t"                                             \
+  "ds_write_b32 v252, v250\n\t"                                       \
+  "s_mov_b64 exec, -1\n\t"                                            \
+  "s_add_u32 %[t], %[t], 1\n\t"                                       \
+  "v_cmp_eq_u32_e32 vcc, s82, %[lid]\n\t"                             \
+  "v_mov_b32_e32 v252, %[t]\n\t"                                      \
+  "v_cndmask_b32_e32 %[lu], %[lu], v252, vcc\n\t"                     \
+  "s_lshl_b32 %[h0], s92, %[hs]\n\t"                                  \
+  "s_branch .Lzh_byte_%=\n"                                           \
+  /* ---- out of line ---- */                                         \
+  ".Lzh_fresh_%=:\n\t"                                                \
+  "ds_read_b32 v252, %[bsa]\n\t"                                      \
+  "s_waitcnt lgkmcnt(0)\n\t"                                          \
+  "v_readfirstlane_b32 %[bdone], v252\n\t"                            \
+  "s_sub_u32 s89, %[t], %[bdone]\n\t"                                 \
+  "s_cmp_gt_u32 s89, s83\n\t"                                         \
+  "s_cbranch_scc0 .Lzh_ok_%=\n\t"                                     \
+  "s_branch .Lzh_slow_%=\n\t"                                         \
+  ZH_FAST_RENORM(0, ZH_FAST_CHK)                                      \
+  ZH_FAST_RENORM(1, ZH_FAST_CHK)                                      \
+  ZH_FAST_RENORM(2, ZH_FAST_CHK)                                      \
+  ZH_FAST_RENORM(3, ZH_FAST_CHK)                                      \
+  ZH_FAST_RENORM(4, ZH_FAST_CHK)                                      \
+  ZH_FAST_RENORM(5, ZH_FAST_CHK)                                      \
+  ZH_FAST_RENORM(6, ZH_FAST_CHK)                                      \
+  ZH_FAST_RENORM(7, ZH_FAST_CHK)                                      \
+  ZH_FAST_RENORM(8, "")                                               \
+  ".Lzh_corrupt_%=:\n\t"                                              \
+  "s_mov_b32 %[code], 1\n\t"                                          \
+  "s_branch .Lzh_end_%=\n"                                            \
+  ".Lzh_slow_%=:\n\t"                                                 \
+  "s_mov_b32 %[code], 0\n"                                            \
+  ".Lzh_end_%=:\n\t"                                                  \
+  : [low] "+s"(low_), [high] "+s"(high_), [curr] "+s"(curr_), [k] "+s"(k_), [t] "+s"(t_), [h0] "+s"(h0_), \
+    [bdone] "+s"(bdone_), [lu] "+v"(lu_), [code] "=s"(code_)          \
+  : [avail] "s"(avail_), [mask] "s"(mask_), [hs] "s"(hs_), [ring] "s"(ring_), [bsa] "v"(bsa_),             \
+    [cur] "v"(cur_), [tag] "v"(tag_), [lid] "v"(lid_), [la] "v"(la_), [lb] "v"(lb_)                        \
+  : "memory", "scc", "vcc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",   \
+    "s91", "s92", "s93", "s94", "v250", "v251", "v252")
+// clang-format on
