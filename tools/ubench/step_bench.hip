@@ -1,0 +1,106 @@
+// Micro-benchmark: cost of the arithmetic-decoder bit step of zh_cm_fast.h on one wavefront,
+// alone on its CU and with a second wavefront of the same workgroup polling LDS (as wave B does).
+// Build: hipcc --offload-arch=gfx950 -O2 step_bench.hip -o step_bench ; run: ./step_bench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+
+#define REP4(x) x x x x
+#define REP16(x) REP4(x) REP4(x) REP4(x) REP4(x)
+#define STAMP(v) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+
+#define STEP                                   \
+  "v_readlane_b32 s94, %[pv], %[j]\n\t"        \
+  "s_sub_u32 s84, %[high], %[low]\n\t"         \
+  "s_sub_u32 s85, %[curr], %[low]\n\t"         \
+  "s_mul_hi_u32 s86, s84, s94\n\t"             \
+  "s_add_u32 s87, %[low], s86\n\t"             \
+  "s_add_u32 s88, s87, 1\n\t"                  \
+  "s_cmp_le_u32 s85, s86\n\t"                  \
+  "s_cselect_b32 %[high], s87, %[high]\n\t"    \
+  "s_cselect_b32 %[low], %[low], s88\n\t"      \
+  "s_addc_u32 %[j], %[j], %[j]\n\t"            \
+  "s_and_b32 %[j], %[j], 63\n\t"               \
+  "s_xor_b32 s84, %[high], %[low]\n\t"         \
+  "s_cmp_lt_u32 s84, 0x100\n\t"                \
+  "s_cbranch_scc1 9f\n\t"
+
+// same arithmetic, range kept as (low, range) so that the multiply does not wait for a subtract
+#define STEP2                                  \
+  "v_readlane_b32 s94, %[pv], %[j]\n\t"        \
+  "s_mul_hi_u32 s86, %[high], s94\n\t"         \
+  "s_sub_u32 s85, %[curr], %[low]\n\t"         \
+  "s_not_b32 s87, s86\n\t"                     \
+  "s_add_u32 s88, %[high], s87\n\t"            \
+  "s_cmp_le_u32 s85, s86\n\t"                  \
+  "s_cselect_b32 %[high], s86, s88\n\t"        \
+  "s_cselect_b32 s87, 0, s87\n\t"              \
+  "s_addc_u32 %[j], %[j], %[j]\n\t"            \
+  "s_and_b32 %[j], %[j], 63\n\t"               \
+  "s_sub_u32 %[low], %[low], s87\n\t"          \
+  "s_cmp_lt_u32 %[high], 0x100\n\t"            \
+  "s_cbranch_scc1 9f\n\t"
+
+__global__ void k(uint64_t *out, uint32_t seed, int spin) {
+  __shared__ uint32_t flag[4];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) flag[0] = 0;
+  __syncthreads();
+  if (wave == 1) {
+    if (!spin) return;
+    for (uint32_t i = 0; i < (1u << 22); ++i) {
+      if (__hip_atomic_load(&flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+      if (spin == 2) __builtin_amdgcn_s_sleep(2);
+    }
+    return;
+  }
+  uint64_t t0, t1;
+  uint32_t low = 1, high = 0xFFFFFFF0u, curr = seed * 2654435761u, j = 1;
+  uint32_t pv = (lane * 2654435761u) | 0x40000000u;
+  int n = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    STAMP(t0);
+    asm volatile(REP16(STEP) "9:\n\t" : [low] "+s"(low), [high] "+s"(high), [curr] "+s"(curr), [j] "+s"(j) : [pv] "v"(pv)
+                 : "scc", "s84", "s85", "s86", "s87", "s88", "s94");
+    STAMP(t1); out[n++] = t1 - t0;
+  }
+  low = 1; high = 0xFFFFFFF0u;
+  for (int rep = 0; rep < 2; ++rep) {
+    STAMP(t0);
+    asm volatile(REP16(STEP2) "9:\n\t" : [low] "+s"(low), [high] "+s"(high), [curr] "+s"(curr), [j] "+s"(j) : [pv] "v"(pv)
+                 : "scc", "s84", "s85", "s86", "s87", "s88", "s94");
+    STAMP(t1); out[n++] = t1 - t0;
+  }
+  // pieces
+  STAMP(t0);
+  asm volatile(REP16("v_readlane_b32 s94, %[pv], %[j]\n\ts_add_u32 %[j], s94, 1\n\ts_and_b32 %[j], %[j], 63\n\t") : [j] "+s"(j) : [pv] "v"(pv) : "scc", "s94");
+  STAMP(t1); out[n++] = t1 - t0;       // readlane(sgpr sel) -> salu -> salu, x16
+  STAMP(t0);
+  asm volatile(REP16("s_mul_hi_u32 %[j], %[j], %[h]\n\ts_add_u32 %[j], %[j], 77\n\t") : [j] "+s"(j) : [h] "s"(high) : "scc");
+  STAMP(t1); out[n++] = t1 - t0;       // mul_hi -> add x16
+  STAMP(t0);
+  asm volatile(REP16("s_cmp_le_u32 %[j], %[h]\n\ts_cselect_b32 %[j], %[h], %[j]\n\t") : [j] "+s"(j) : [h] "s"(high) : "scc");
+  STAMP(t1); out[n++] = t1 - t0;       // cmp -> cselect x16
+  STAMP(t0);
+  STAMP(t1); out[n++] = t1 - t0;
+  out[n++] = low + high + curr + j;
+  if (lane == 0) __hip_atomic_store(&flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+int main() {
+  uint64_t *d;
+  hipMalloc(&d, 256);
+  const char *names[] = {"STEP x16 (cold)", "STEP x16", "STEP2 x16 (cold)", "STEP2 x16", "readlane->2 salu x16 (48)", "mul_hi->add x16 (32)",
+                         "cmp->cselect x16 (32)", "empty stamp pair"};
+  for (int spin = 0; spin < 3; ++spin) {
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL(k, dim3(1), dim3(128), 0, 0, d, 12345u, spin);
+      hipDeviceSynchronize();
+    }
+    uint64_t o[32];
+    hipMemcpy(o, d, 256, hipMemcpyDeviceToHost);
+    printf("second wave: %s\n", spin == 0 ? "exits at once" : spin == 1 ? "polls LDS flat out" : "polls LDS with s_sleep 2");
+    for (int i = 0; i < 8; ++i) printf("  %-32s %6llu cycles\n", names[i], (unsigned long long)o[i]);
+  }
+  return 0;
+}

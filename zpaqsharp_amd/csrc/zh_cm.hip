@@ -144,7 +144,7 @@ __device__ __forceinline__ uint32_t win_miss(uint32_t w, uint32_t &tag, uint32_t
 // ---------------------------------------------------------------------------------------
 template <bool PROF>
 __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
-  uint64_t busy = 0, tb0 = 0, tb1 = 0;
+  uint64_t busy = 0, tb0 = 0, tb1 = 0, idle = 0;
   const uint32_t l15 = lane & 15;
   const uint32_t ltt = 31 - __clz((int)(l15 | 1));
   const uint32_t lsh_vis = 4 - ltt, lsh_y = 3 - ltt;
@@ -173,40 +173,62 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     lds_st(&S.cmd_ack, cs);
 
-    for (uint32_t u = 0;; ++u) {
-      uint32_t sp = 0, m0;
-      const uint32_t want = ring_tag(u);
-      for (;;) {                                            // next message
-        m0 = uni(lds_ld(&S.ring[u & (kRing - 1)]));
-        if (LIKELY((m0 >> 25) == want)) break;
-        if (++sp > kSpinSection) return;
-      }
-      lds_order();
-      if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0)::"memory"); }
+    // Byte messages run as a two-stage pipeline so that the LDS round trips of consecutive bytes
+    // overlap: stage 1 of byte u (read entry, read dt, train, write entry) is issued together with
+    // stage 2 of byte u-1 (stretch, squash, write the cached probability, report completion).
+    // LDS requests are served in issue order, so byte u reads the entries byte u-1 wrote.
+    uint32_t u = 0, sp = 0;
+    bool pend = false, leave = false;                      // stage 2 of message u-1 outstanding
+    uint32_t p_nv = 0, p_pos = 0;                          // per lane: trained entry, its p16 index
+    bool p_vis = false;
+    auto stretch_idx = [&](uint32_t nv) { const uint32_t xv = nv >> 17; return xv >= 16384 ? xv - 16384 : 16383 - xv; };
+    while (!leave) {
+      const uint32_t m0 = uni(lds_ld(&S.ring[u & (kRing - 1)]));
+      const bool have = (m0 >> 25) == ring_tag(u);
       const uint32_t type = (m0 >> 23) & 3, slot = m0 & 63;
-      if (LIKELY(type == kMsgByte)) {
+      lds_order();
+      if (LIKELY(have && type == kMsgByte)) {
+        if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0)::"memory"); }
+        sp = 0;
         const uint32_t lo9 = (m0 >> 6) & 511, c = (m0 >> 15) & 255;
         const uint32_t g0 = lo9 >> 4, x = lo9 & 15, n1 = c >> 4, n2 = c & 15;
-        // lanes 0-15: entries of the first nibble; lanes 16-31: second nibble (group (g0^16)^n1)
-        const bool second = lane >= 16;
+        // lanes 0-15 (and their copies 32-47): entries of the first nibble; lanes 16-31: second nibble, group (g0^16)^n1
+        const bool second = (lane & 16) != 0;
         const uint32_t grp = second ? ((g0 ^ 16) ^ n1) : g0;
         const uint32_t idx = (grp << 4) | (l15 ^ x);
         const uint32_t nib = second ? n2 : n1;
         const bool vis = lane < 32 && l15 != 0 && l15 == ((16 | nib) >> lsh_vis);
-        if (vis) {                                         // Predictor.train (Predictor.cs:1031-1036)
-          const uint32_t cm = S.win[slot][idx];
-          const uint32_t yy = (nib >> lsh_y) & 1, cnt = cm & 0x3ff;
-          const int err = (int)(yy * 32767) - (int)(cm >> 17);
-          const uint32_t nv = cm + (((uint32_t)err * (uint32_t)S.dt[cnt]) & 0xFFFFFC00u) + (cnt < limit);
-          S.win[slot][idx] = nv;
-          S.p16[slot][p16_pos(idx)] = (uint16_t)p16_of(S, nv);
+        // every lane reads (harmless for the unvisited ones); only the writes are masked
+        const uint32_t cm = S.win[slot][idx];                           // stage 1
+        const int shv = S.sh[stretch_idx(p_nv)];                        // stage 2 of the previous byte
+        const uint32_t cnt = cm & 0x3ff;
+        const int dtv = S.dt[cnt];
+        const uint32_t sqv = S.sq[((p_nv >> 17) >= 16384 ? shv : -shv) + 2048];
+        const uint32_t yy = (nib >> lsh_y) & 1;
+        const int err = (int)(yy * 32767) - (int)(cm >> 17);            // Predictor.train (Predictor.cs:1031-1036)
+        const uint32_t nv = cm + (((uint32_t)err * (uint32_t)dtv) & 0xFFFFFC00u) + (cnt < limit);
+        if (vis) S.win[slot][idx] = nv;
+        if (pend) {
+          if (p_vis) (&S.p16[0][0])[p_pos] = (uint16_t)(sqv * 2 + 1);
+          lds_order();
+          lds_put0(&S.b_seq, u);                                        // messages 0..u-1 are complete
         }
-        lds_order();
-        lds_put0(&S.b_seq, u + 1);
+        p_nv = nv; p_pos = slot * 512 + p16_pos(idx); p_vis = vis; pend = true;
+        ++u;
         out_put(ob, c, lane);                              // PostProcessor PASS: the byte is the plaintext
         if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1)::"memory"); busy += tb1 - tb0; }
-        continue;
+      } else if (pend) {                                   // nothing new: finish the outstanding byte
+        const int shv = S.sh[stretch_idx(p_nv)];
+        const uint32_t sqv = S.sq[((p_nv >> 17) >= 16384 ? shv : -shv) + 2048];
+        if (p_vis) (&S.p16[0][0])[p_pos] = (uint16_t)(sqv * 2 + 1);
+        lds_order();
+        lds_put0(&S.b_seq, u);
+        pend = false;
+      } else if (!have) {
+        if (PROF) ++idle;
+        if (++sp > kSpinSection) return;
       } else if (type == kMsgMiss) {
+        sp = 0;
         const uint32_t neww = uni(S.aux[u & (kRing - 1)][0]), oldw = uni(S.aux[u & (kRing - 1)][1]);
         uint4 *l = reinterpret_cast<uint4 *>(&S.win[slot][0]);
         if (oldw != kNoWin) {                              // write the victim back (coalesced, 2 x 1 KiB)
@@ -220,21 +242,22 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
         l[lane + 64] = b;
         wave_sync();
         for (uint32_t i = lane; i < 512; i += 64) S.p16[slot][p16_pos(i)] = (uint16_t)p16_of(S, S.win[slot][i]);
+        ++u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lds_st(&S.b_seq, u);
       } else {                                             // LEAVE: hand the output state back
         out_flush(ob, lane);
         if (PROF && lane == 0 && L.debug) {
           atomicAdd((unsigned long long *)&L.debug[5], (unsigned long long)busy);
-          uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-          if (((hw >> 4) & 3) == S.pad0) atomicAdd((unsigned long long *)&L.debug[7], 1ull);
+          atomicAdd((unsigned long long *)&L.debug[7], (unsigned long long)idle);
         }
-        busy = 0;
+        busy = 0; idle = 0;
         if (lane == 0) { S.ob_len = ob.len; S.ob_stored = ob.stored; S.ob_word = ob.word; S.ob_room = ob.room; }
+        ++u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        lds_st(&S.b_seq, u + 1);
-        break;
+        lds_st(&S.b_seq, u);
+        leave = true;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      lds_st(&S.b_seq, u + 1);
     }
   }
 }
@@ -510,7 +533,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
           uint32_t tq;
           // hand-written loop for the common case (zh_cm_fast.h); the C++ body below is the same
           // algorithm and takes every byte the fast loop declines
-          const bool fast_ok = !PROF && hshift >= 9 && hshift < 32;
+          const bool fast_ok = hshift >= 9 && hshift < 32;
           const uint32_t fast_la = p16_base + (l15 << 3), fast_lb = p16_base + 512 + lgrp * 128 + (l15 << 3);
           const uint32_t fast_ring = (uint32_t)(uintptr_t)&S.ring[0], fast_bsa = (uint32_t)(uintptr_t)&S.b_seq;
           for (;;) {
@@ -519,8 +542,12 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
               uint32_t code;
               d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr); in.k = uni(in.k); in.avail = uni(in.avail);
               t = uni(t); h0 = uni(h0); b_done = uni(b_done);
+              uint64_t f0 = 0, f1 = 0;
+              const uint32_t t_in = t;
+              if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(f0)::"memory"); }
               ZH_CM_FAST_LOOP(d.low, d.high, d.curr, in.k, t, h0, b_done, lastuse, code, in.avail, uni(cm_mask), uni(hshift),
                               uni(fast_ring), fast_bsa, in.cur, tag, lane, fast_la, fast_lb);
+              if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(f1)::"memory"); prof[2] += f1 - f0; prof[3] += t - t_in; }
               if (UNLIKELY(code)) { ev = kEvCorrupt; d.low = d.high = d.curr = 1; }   // the EOS test below ends the section
             }
             if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
@@ -569,7 +596,6 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
             const uint32_t s_b = s_win + (((g0 >> 4) ^ 1) << 9);
             const uint32_t pa = (uint32_t)lds_u16(p16_base + s_a + pos8) << 16;
             const uint64_t pb = lds_u64(lane_b + s_b + pos8);
-            ZH_STAMP(2);
             uint32_t j = 1;
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
@@ -581,7 +607,6 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
                 if (dec_renorm_chk(d, in, lane, bad) && !err) err = was ? kEvCorrupt : kEvEof;
               }
             }
-            ZH_STAMP(3);
             // second nibble: group (g0 ^ n1) & 15 of the other half = quad (ga & 3), element ga >> 2
             const uint32_t ga = uni((g0 ^ j) & 15), lb = (ga & 3) * 16;
             const uint32_t psel = (uint32_t)(pb >> ((ga >> 2) * 16)) << 16;

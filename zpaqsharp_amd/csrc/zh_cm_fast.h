@@ -6,11 +6,12 @@
 //
 // The loop only runs when nothing unusual can happen inside the byte.  It checks, before it
 // changes any state, that
-//   * the coder is primed (curr != 0) and at least 40 coded bytes are in the register-held chunk
-//     (a byte consumes at most 9 x 4), so a renormalisation never has to refill or can hit EOF;
+//   * at least 40 coded bytes are in the register-held chunk (a byte consumes at most 9 x 4), so
+//     a renormalisation never has to refill or can hit EOF;
 //   * the context's window is resident (otherwise wave B must swap it in);
 //   * wave B has finished every earlier byte that touched that window and the ring has room;
-//   * the EOS flag decodes as 0 and the state is in range (Decoder.cs:138).
+//   * the EOS flag decodes as 0 and the state is in range (Decoder.cs:138); an unprimed coder
+//     (curr == 0 < low) fails this test too, so priming needs no test of its own.
 // If any test fails it leaves with code 0 and the C++ body of the loop in zh_cm.hip handles that
 // byte (it is the same algorithm, including the rare cases), then re-enters.  Code 1 = the range
 // check after a renormalisation failed ("archive corrupted").
@@ -75,8 +76,6 @@
 #define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, avail_, mask_, hs_, ring_, bsa_, cur_, tag_, lid_, la_, lb_) \
   asm volatile(                                                       \
   ".Lzh_byte_%=:\n\t"                                                 \
-  "s_cmp_eq_u32 %[curr], 0\n\t"                                       \
-  "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
   "s_sub_u32 s80, %[avail], %[k]\n\t"                                 \
   "s_cmp_lt_u32 s80, 40\n\t"                                          \
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
@@ -161,13 +160,19 @@
   "s_lshl_b32 %[h0], s92, %[hs]\n\t"                                  \
   "s_branch .Lzh_byte_%=\n"                                           \
   /* ---- out of line ---- */                                         \
+  /* wave B is behind: re-read its progress counter a bounded number of times, then give up */ \
   ".Lzh_fresh_%=:\n\t"                                                \
+  "s_mov_b32 s80, 48\n"                                               \
+  ".Lzh_spin_%=:\n\t"                                                 \
   "ds_read_b32 v252, %[bsa]\n\t"                                      \
   "s_waitcnt lgkmcnt(0)\n\t"                                          \
   "v_readfirstlane_b32 %[bdone], v252\n\t"                            \
   "s_sub_u32 s89, %[t], %[bdone]\n\t"                                 \
   "s_cmp_gt_u32 s89, s83\n\t"                                         \
   "s_cbranch_scc0 .Lzh_ok_%=\n\t"                                     \
+  "s_sub_u32 s80, s80, 1\n\t"                                         \
+  "s_cmp_lg_u32 s80, 0\n\t"                                           \
+  "s_cbranch_scc1 .Lzh_spin_%=\n\t"                                   \
   "s_branch .Lzh_slow_%=\n\t"                                         \
   ZH_FAST_RENORM(0, ZH_FAST_CHK)                                      \
   ZH_FAST_RENORM(1, ZH_FAST_CHK)                                      \
