@@ -99,6 +99,45 @@ def test_cm_models_with_other_shapes(ctx):
     assert ctx.decompress(s, verify_sha1=True).tobytes() == x
 
 
+def test_two_wave_cm_kernel_stress(ctx):
+    """zh_cm.hip's decoder/helper split: shift forms that use the assembly loop (K >= 9) and the C++ body (K < 9),
+    wide tables (window ids beyond one byte), data that thrashes the 36-window LDS cache (evictions, write-backs,
+    reloads), runs of one byte (every byte waits for the helper wave's update of the same window), and several
+    segments per block (the section is left and re-entered)."""
+    rng = np.random.default_rng(77)
+    n = 150000
+    runs = np.repeat(rng.integers(0, 256, n // 50, dtype=np.uint8), 50).tobytes()
+    rand = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    few = rng.integers(0, 40, n, dtype=np.uint8).tobytes()          # just over the cache size: steady misses
+    text = util.text(n, seed=12)
+    cfgs = ["comp 0 0 0 0 1 0 cm 17 255 hcomp a<<= 9 *d=a halt end",
+            "comp 0 0 0 0 1 0 cm 16 255 hcomp a<<= 8 *d=a halt end",      # low context bits not zero: C++ body
+            "comp 0 0 0 0 1 0 cm 22 20 hcomp a<<= 14 *d=a halt end",      # window id = byte << 5
+            "comp 0 0 0 0 1 0 cm 12 255 hcomp a<<= 10 *d=a halt end"]     # table smaller than the cache
+    for cfg in cfgs:
+        m = zpaql.assemble(cfg)
+        for data in (runs, rand, few, text):
+            s = synth.compress_block(m, data)
+            assert ctx.decompress(s, verify_sha1=True).tobytes() == data, cfg
+    # the oracle agrees on one of each (keeps the CPU time of this test small)
+    m = zpaql.assemble(cfgs[1])
+    assert oracle.decompress(synth.compress_block(m, few[:40000])) == few[:40000]
+    # multi-segment block through the Compressor mirror: the window cache survives the segment boundary
+    m = models.get("l1")
+    parts = [rand[:30000], b"", runs[:20000], text[:50000]]
+    c = oracle.Compressor(400000)
+    c.write_tag(); c.start_block(m.header)
+    for i, part in enumerate(parts):
+        c.start_segment(b"f%d" % i, str(len(part)).encode())
+        if i == 0:
+            c.post_process(m.pcomp)
+        c.compress(part)
+        c.end_segment(oracle.sha1(part))
+    c.end_block()
+    s = c.getvalue()
+    assert ctx.decompress(s, verify_sha1=True).tobytes() == b"".join(parts)
+
+
 def test_multi_segment_blocks(ctx):
     for model in ("l1", "mid", "max+e8e9"):
         m = models.get(model)
