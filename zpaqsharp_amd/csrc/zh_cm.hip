@@ -1,43 +1,34 @@
-// zh_cm.hip — lane-parallel decode kernel for models that are ONE direct context
-// model (n == 1, component CM with >= 9 size bits): BASELINE configs 1-2 ("L1").
+// zh_cm.hip — two-wave decode kernel for models that are ONE direct context model whose HCOMP is
+// "a<<= K  *d=a  halt" with K >= 9 (n == 1, component CM): BASELINE configs 1-2 ("L1").
 //
-// One wavefront owns one block.  What makes this path MI355X-shaped:
+// One workgroup of two wavefronts owns one block.  What makes this path MI355X-shaped:
 //
-//  * The CM table slice a byte can touch is one 2 KiB "window": the context
-//    index is h[0] ^ hmap4 with hmap4 < 512 (Predictor.cs:263-266, :463-474), so
-//    all 8 bit-contexts of a byte lie in the 512 entries around h[0].  Windows
-//    are cached in LDS (44 x 2 KiB, fully associative: one tag per lane, lookup =
-//    one v_cmp + s_ff1; FIFO replacement).  For text-like data every context
-//    window stays in LDS for the whole block, so HBM sees only the stream and the
-//    plaintext.  Victims are written back / windows loaded with coalesced 16-byte
-//    accesses.
-//  * Within a byte each bit position uses a DIFFERENT table entry, so all the
-//    probabilities a byte can need (15 for the first nibble, 240 for the second)
-//    are looked up at once by the 64 lanes (squash(stretch(cm>>17)) fused into
-//    one 64 KiB LDS table); lane j of a 16-lane group holds the entry of nibble
-//    context j, so the bit-serial decoder selects with v_readlane(j).
-//  * The arithmetic decoder (Decoder.decode, Decoder.cs:136-158) is a hand-
-//    scheduled 14-instruction scalar sequence per bit.  A lone wave on a CU pays
-//    ~4 cycles per instruction and ~20 per taken branch (tools/ubench), so the hot
-//    path is straight-line: errors and renormalisation are flags tested with
-//    not-taken branches, and (range*p)>>16 is one s_mul_hi_u32 against p<<16.
-//  * The 8 entries a byte visited are trained by 8 lanes at once afterwards
-//    (Predictor.train, Predictor.cs:486-493 / :1031-1036).
-//  * Compressed bytes come from a 256-byte register buffer (one aligned dword per
-//    lane); plaintext is packed into dwords on the scalar unit, parked in a VGPR
-//    with v_writelane and leaves as one coalesced 256-byte store per 256 bytes.
+//  * The CM table slice a byte can touch is one 512-entry "window": the context index is
+//    h[0] ^ hmap4 with hmap4 < 512 (Predictor.cs:263-266, :463-474).  With K >= 9 the low 9 bits of
+//    h[0] are zero, so a byte uses group 0 of the window for its first nibble and one of the groups
+//    16..31 for its second: 272 of the 512 entries.  Those 272 entries of up to 64 windows are
+//    cached in LDS (fully associative: one tag per lane, lookup = one v_cmp + s_ff1; LRU), each
+//    together with its ready-made 16-bit decoder probability squash(stretch(cm >> 17)) * 2 + 1.
+//    For text-like data every context window stays in LDS for the whole block, so HBM sees only the
+//    stream and the plaintext.  Victims are written back / windows loaded with 16-byte accesses.
+//  * WAVE A runs nothing but the arithmetic decoder (Decoder.decode, Decoder.cs:136-158) against
+//    that probability cache; its byte loop is hand-written assembly (zh_cm_fast.h).  Within a byte
+//    each bit uses a DIFFERENT entry, so all probabilities the byte can need are fetched at once
+//    (lane j <- first-nibble node j; lane (q, j) <- node j of second-nibble groups q, q+4, q+8, q+12)
+//    and the bit-serial decoder selects with v_readlane.
+//  * WAVE B, on its own SIMD of the same CU, receives each decoded byte through an LDS ring, trains
+//    the 8 entries it visited (Predictor.train, Predictor.cs:486-493 / :1031-1036) with 8 lanes,
+//    refreshes their cached probabilities and writes the plaintext (dwords packed on the scalar
+//    unit, parked in a VGPR, one coalesced 256-byte store per 256 bytes).  It also swaps windows.
+//  * The only true dependency — a byte whose window was touched by a byte B has not finished — is
+//    tracked per window slot; the same per-slot stamp is the LRU clock.
+//  * Compressed bytes come from a 256-byte register buffer (one aligned dword per lane).
 //
-//  * TWO wavefronts share the block while the PASS post-processor is active (the steady
-//    state): wave A runs nothing but the arithmetic decoder against a cache of ready-made
-//    16-bit probabilities (one per table entry of every resident window); wave B, on its own
-//    SIMD of the same CU, receives each decoded byte through an LDS ring, trains the 8
-//    entries it visited, refreshes their cached probabilities and writes the plaintext.
-//    The only true dependency — a byte whose window was touched by a byte B has not
-//    finished yet — is tracked per window and makes A wait on B's progress counter.
-//
-// Anything this kernel does not specialise (PCOMP programs, unusual HCOMP) runs
-// through the same scalar core as the generic kernel, still on the GPU (wave A alone).
+// The first bytes of a segment (post-processor header) and PCOMP programs run on wave A alone
+// through the scalar core shared with the generic kernel, on the same window cache.  Single-CM
+// models of any other shape are decoded by zh_chain.hip / zh_generic.hip (zh_framing.cpp decides).
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "zh_core.h"
@@ -50,7 +41,7 @@ using namespace zhdev;
 
 namespace {
 
-constexpr int kWin = 36;                  // LDS-resident CM windows (2 KiB entries + 1 KiB cached probabilities each)
+constexpr uint32_t kWin = 64;             // LDS-resident windows: one tag per lane of wave A
 constexpr uint32_t kNoWin = 0xFFFFFFFFu;
 constexpr uint32_t kRing = 16;            // A -> B message ring (entries)
 enum : uint32_t { kMsgByte = 0, kMsgMiss = 1, kMsgLeave = 2 };
@@ -63,18 +54,19 @@ struct alignas(16) CmLds {
   int16_t sh[16384];                      // stretch(x) for x in [16384, 32768); stretch(x) = -stretch(32767 - x) below
   uint16_t sq[4096];                      // squash
   int32_t dt[1024];
-  uint32_t win[kWin][512];                // CM entries of the resident windows
-  uint16_t p16[kWin][512];                // predict()*2+1 of every entry, kept current by wave B in the steady state
-  uint32_t ring[kRing];                   // A -> B messages: tag(7) | type(2) | byte(8) | lo9(9) | slot(6)
+  uint32_t winB[kWin][256];               // CM entries of groups 16..31 of the resident windows (second nibble)
+  uint32_t winA[kWin][16];                // CM entries of group 0 (first nibble)
+  uint16_t p16B[kWin][256];               // predict()*2+1 of every winB entry, order p16b_pos; kept current by wave B
+  uint16_t p16A[kWin][16];                // same for winA
+  uint32_t ring[kRing];                   // A -> B messages: tag(7) | type(2) | byte(8) | 0(9) | slot(6)
   uint32_t aux[kRing][2];                 // MISS: new window, victim window
   uint32_t tags[64];                      // window directory handed to B on ENTER
-  uint32_t a_seq, b_seq;                  // messages published by A / completed by B in this section
+  uint32_t t0, b_seq;                     // message count at section start / messages completed by B
   uint32_t cmd_seq, cmd_code, cmd_ack;    // A -> B commands outside a section
-  uint32_t limit, ob_word, ob_room, pad0;
+  uint32_t limit, ob_word, ob_room;
   uint64_t table, ob_base, ob_cap, ob_len, ob_stored;
-  uint32_t r[256];                        // HCOMP R (generic HCOMP fallback)
   uint32_t pr[256];                       // PCOMP R
-  Vm hz, pz;                              // cold machine state lives here, not in registers
+  Vm pz;                                  // cold machine state lives here, not in registers
   Sink sink;                              // output of a PCOMP program
 };
 static_assert(sizeof(CmLds) <= 163840, "LDS budget");
@@ -85,7 +77,6 @@ __device__ __forceinline__ uint32_t lds_ld(const uint32_t *p) {
 __device__ __forceinline__ void lds_st(uint32_t *p, uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// single-wave replacement of __syncthreads(): wave A must never wait on a workgroup barrier (wave B idles in a mailbox loop)
 // One dword into LDS from lane 0 only, without the compiler's exec-mask dance.  The calling wave
 // runs with all 64 lanes enabled (uniform code), so exec is restored to all ones.
 __device__ __forceinline__ void lds_put0(const uint32_t *where, uint32_t val) {
@@ -96,20 +87,20 @@ __device__ __forceinline__ void lds_put0(const uint32_t *where, uint32_t val) {
 // in program order, so "write data, then write flag" / "read flag, then read data" need no
 // s_waitcnt between them: only the compiler must not reorder.
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
-// Typed LDS reads by LDS byte offset (keeps ds_read_* with folded address arithmetic).
-typedef __attribute__((address_space(3))) const uint16_t *lds_u16_p;
+// Typed LDS accesses by LDS byte offset (keeps ds_* with folded address arithmetic).
+typedef __attribute__((address_space(3))) uint16_t *lds_u16_p;
+typedef __attribute__((address_space(3))) uint32_t *lds_u32_p;
 typedef __attribute__((address_space(3))) const uint64_t *lds_u64_p;
 __device__ __forceinline__ uint32_t lds_u16(uint32_t off) { return *(lds_u16_p)off; }
 __device__ __forceinline__ uint64_t lds_u64(uint32_t off) { return *(lds_u64_p)off; }
-// Where the probability of window entry e (group G = e >> 4, position P = e & 15) is kept inside
-// p16[slot][]: half H = G >> 4, then quad G & 3, position, element (G >> 2) & 3 — so that a lane's
-// four second-nibble candidates (groups q, q+4, q+8, q+12 of one half, same position) are adjacent.
-__device__ __forceinline__ uint32_t p16_pos(uint32_t e) {
-  const uint32_t G = e >> 4, P = e & 15;
-  return ((G >> 4) << 8) | ((G & 3) << 6) | (P << 2) | ((G >> 2) & 3);
-}
+__device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(uintptr_t)p; }
+// Where the probability of second-nibble entry (group 16 + q, position P) is kept inside p16B[slot][]:
+// quad q & 3, position, element q >> 2 — so that the four candidates of a lane of wave A (groups
+// q, q+4, q+8, q+12, same position) are adjacent: one ds_read_b64.
+__device__ __forceinline__ uint32_t p16b_pos(uint32_t q, uint32_t P) { return ((q & 3) << 6) | (P << 2) | (q >> 2); }
 __device__ __forceinline__ uint32_t ring_tag(uint32_t u) { return (u >> 4) & 127u; }   // kRing == 16
 static_assert(kRing == 16, "ring_tag");
+// single-wave replacement of __syncthreads(): wave A must never wait on a workgroup barrier (wave B idles in a mailbox loop)
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
 // predict()*2+1 for a CM entry: squash(stretch(cm >> 17)) (Predictor.cs:263-266, :349) through the half stretch table
@@ -119,24 +110,37 @@ __device__ __forceinline__ uint32_t p16_of(const CmLds &S, uint32_t cm) {
   return (uint32_t)S.sq[st + 2048] * 2 + 1;
 }
 
-// Window cache miss: pick the next FIFO victim, write it back, load window w.
-__device__ __forceinline__ uint32_t win_miss(uint32_t w, uint32_t &tag, uint32_t &fifo, CmLds &S, uint32_t *table,
-                                          uint32_t lane) {
-  const uint32_t slot = fifo;
-  fifo = fifo + 1 == (uint32_t)kWin ? 0 : fifo + 1;
-  const uint32_t old = rdlane(tag, slot);
-  uint4 *l = reinterpret_cast<uint4 *>(&S.win[slot][0]);
-  if (old != kNoWin) {                    // write the victim back (coalesced, 2 x 1 KiB)
-    uint4 *g = reinterpret_cast<uint4 *>(table + (uint64_t)old * 512);
-    g[lane] = l[lane];
-    g[lane + 64] = l[lane + 64];
+// Window <-> table (reference layout in HBM: 512 entries per window; group 0 = uint4 0..3, groups 16..31 = uint4 64..127)
+__device__ __forceinline__ void win_store(const CmLds &S, uint32_t slot, uint32_t *table, uint32_t w, uint32_t lane) {
+  uint4 *g = reinterpret_cast<uint4 *>(table + (uint64_t)w * 512);
+  g[64 + lane] = reinterpret_cast<const uint4 *>(&S.winB[slot][0])[lane];
+  if (lane < 4) g[lane] = reinterpret_cast<const uint4 *>(&S.winA[slot][0])[lane];
+}
+__device__ __forceinline__ void win_load(CmLds &S, uint32_t slot, const uint32_t *table, uint32_t w, uint32_t lane) {
+  const uint4 *g = reinterpret_cast<const uint4 *>(table + (uint64_t)w * 512);
+  const uint4 b = g[64 + lane];
+  uint4 a = make_uint4(0, 0, 0, 0);
+  if (lane < 4) a = g[lane];
+  reinterpret_cast<uint4 *>(&S.winB[slot][0])[lane] = b;
+  if (lane < 4) reinterpret_cast<uint4 *>(&S.winA[slot][0])[lane] = a;
+}
+// probability cache of one slot from its entries (whole wave)
+__device__ __forceinline__ void p16_rebuild(CmLds &S, uint32_t slot, uint32_t lane) {
+#pragma unroll
+  for (uint32_t k = 0; k < 4; ++k) {
+    const uint32_t e = lane + 64 * k;
+    S.p16B[slot][p16b_pos(e >> 4, e & 15)] = (uint16_t)p16_of(S, S.winB[slot][e]);
   }
-  const uint4 *gn = reinterpret_cast<const uint4 *>(table + (uint64_t)w * 512);
-  uint4 a = gn[lane], b = gn[lane + 64];
-  l[lane] = a;
-  l[lane + 64] = b;
-  if (lane == slot) tag = w;
-  return slot;
+  if (lane < 16) S.p16A[slot][lane] = (uint16_t)p16_of(S, S.winA[slot][lane]);
+}
+// Replacement: an empty slot if there is one, else the slot whose last use is oldest (lane s holds slot s's stamp).
+__device__ __forceinline__ uint32_t pick_victim(uint32_t tag, uint32_t lastuse, uint32_t now) {
+  const uint64_t empty = __ballot(tag == kNoWin);
+  if (empty) return (uint32_t)__builtin_ctzll(empty);
+  const uint32_t age = now - lastuse;
+  uint32_t m = age;
+  for (int d = 32; d; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)m, d); m = o > m ? o : m; }
+  return (uint32_t)__builtin_ctzll(__ballot(age == m));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -148,6 +152,8 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
   const uint32_t l15 = lane & 15;
   const uint32_t ltt = 31 - __clz((int)(l15 | 1));
   const uint32_t lsh_vis = 4 - ltt, lsh_y = 3 - ltt;
+  const uint32_t offA = lds_off(&S.winA[0][0]) + l15 * 4, offB = lds_off(&S.winB[0][0]) + l15 * 4;
+  const uint32_t poffA = lds_off(&S.p16A[0][0]) + l15 * 2, poffB = lds_off(&S.p16B[0][0]);
   uint32_t seen = 0;
   for (;;) {
     uint64_t spin = 0;
@@ -166,10 +172,11 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
     OutBuf ob;
     ob.base = L.out + uni64(S.ob_base); ob.cap = uni64(S.ob_cap); ob.len = uni64(S.ob_len);
     ob.stored = uni64(S.ob_stored); ob.word = uni(S.ob_word); ob.room = uni(S.ob_room); ob.park = 0;
-    for (uint32_t sl = 0; sl < (uint32_t)kWin; ++sl) {
+    for (uint32_t sl = 0; sl < kWin; ++sl) {
       if (uni(S.tags[sl]) == kNoWin) continue;
-      for (uint32_t i = lane; i < 512; i += 64) S.p16[sl][p16_pos(i)] = (uint16_t)p16_of(S, S.win[sl][i]);
+      p16_rebuild(S, sl, lane);
     }
+    uint32_t u = uni(S.t0), sp = 0;                        // next message to take
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     lds_st(&S.cmd_ack, cs);
 
@@ -177,9 +184,8 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
     // overlap: stage 1 of byte u (read entry, read dt, train, write entry) is issued together with
     // stage 2 of byte u-1 (stretch, squash, write the cached probability, report completion).
     // LDS requests are served in issue order, so byte u reads the entries byte u-1 wrote.
-    uint32_t u = 0, sp = 0;
     bool pend = false, leave = false;                      // stage 2 of message u-1 outstanding
-    uint32_t p_nv = 0, p_pos = 0;                          // per lane: trained entry, its p16 index
+    uint32_t p_nv = 0, p_off = 0;                          // per lane: trained entry, LDS offset of its p16
     bool p_vis = false;
     auto stretch_idx = [&](uint32_t nv) { const uint32_t xv = nv >> 17; return xv >= 16384 ? xv - 16384 : 16383 - xv; };
     while (!leave) {
@@ -190,16 +196,15 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
       if (LIKELY(have && type == kMsgByte)) {
         if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0)::"memory"); }
         sp = 0;
-        const uint32_t lo9 = (m0 >> 6) & 511, c = (m0 >> 15) & 255;
-        const uint32_t g0 = lo9 >> 4, x = lo9 & 15, n1 = c >> 4, n2 = c & 15;
-        // lanes 0-15 (and their copies 32-47): entries of the first nibble; lanes 16-31: second nibble, group (g0^16)^n1
+        const uint32_t c = (m0 >> 15) & 255, n1 = c >> 4, n2 = c & 15;
+        // lanes 0-15 (and their copies 32-47): entries of the first nibble (group 0);
+        // lanes 16-31 (48-63): second nibble, group 16 + n1
         const bool second = (lane & 16) != 0;
-        const uint32_t grp = second ? ((g0 ^ 16) ^ n1) : g0;
-        const uint32_t idx = (grp << 4) | (l15 ^ x);
         const uint32_t nib = second ? n2 : n1;
         const bool vis = lane < 32 && l15 != 0 && l15 == ((16 | nib) >> lsh_vis);
+        const uint32_t eoff = second ? offB + slot * 1024 + n1 * 64 : offA + slot * 64;
         // every lane reads (harmless for the unvisited ones); only the writes are masked
-        const uint32_t cm = S.win[slot][idx];                           // stage 1
+        const uint32_t cm = *(lds_u32_p)eoff;                           // stage 1
         const int shv = S.sh[stretch_idx(p_nv)];                        // stage 2 of the previous byte
         const uint32_t cnt = cm & 0x3ff;
         const int dtv = S.dt[cnt];
@@ -207,20 +212,21 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
         const uint32_t yy = (nib >> lsh_y) & 1;
         const int err = (int)(yy * 32767) - (int)(cm >> 17);            // Predictor.train (Predictor.cs:1031-1036)
         const uint32_t nv = cm + (((uint32_t)err * (uint32_t)dtv) & 0xFFFFFC00u) + (cnt < limit);
-        if (vis) S.win[slot][idx] = nv;
+        if (vis) *(lds_u32_p)eoff = nv;
         if (pend) {
-          if (p_vis) (&S.p16[0][0])[p_pos] = (uint16_t)(sqv * 2 + 1);
+          if (p_vis) *(lds_u16_p)p_off = (uint16_t)(sqv * 2 + 1);
           lds_order();
-          lds_put0(&S.b_seq, u);                                        // messages 0..u-1 are complete
+          lds_put0(&S.b_seq, u);                                        // every message before u is complete
         }
-        p_nv = nv; p_pos = slot * 512 + p16_pos(idx); p_vis = vis; pend = true;
+        p_nv = nv; p_vis = vis; pend = true;
+        p_off = second ? poffB + slot * 512 + p16b_pos(n1, l15) * 2 : poffA + slot * 32;
         ++u;
         out_put(ob, c, lane);                              // PostProcessor PASS: the byte is the plaintext
         if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1)::"memory"); busy += tb1 - tb0; }
       } else if (pend) {                                   // nothing new: finish the outstanding byte
         const int shv = S.sh[stretch_idx(p_nv)];
         const uint32_t sqv = S.sq[((p_nv >> 17) >= 16384 ? shv : -shv) + 2048];
-        if (p_vis) (&S.p16[0][0])[p_pos] = (uint16_t)(sqv * 2 + 1);
+        if (p_vis) *(lds_u16_p)p_off = (uint16_t)(sqv * 2 + 1);
         lds_order();
         lds_put0(&S.b_seq, u);
         pend = false;
@@ -230,18 +236,10 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
       } else if (type == kMsgMiss) {
         sp = 0;
         const uint32_t neww = uni(S.aux[u & (kRing - 1)][0]), oldw = uni(S.aux[u & (kRing - 1)][1]);
-        uint4 *l = reinterpret_cast<uint4 *>(&S.win[slot][0]);
-        if (oldw != kNoWin) {                              // write the victim back (coalesced, 2 x 1 KiB)
-          uint4 *g = reinterpret_cast<uint4 *>(table + (uint64_t)oldw * 512);
-          g[lane] = l[lane];
-          g[lane + 64] = l[lane + 64];
-        }
-        const uint4 *gn = reinterpret_cast<const uint4 *>(table + (uint64_t)neww * 512);
-        const uint4 a = gn[lane], b = gn[lane + 64];
-        l[lane] = a;
-        l[lane + 64] = b;
+        if (oldw != kNoWin) win_store(S, slot, table, oldw, lane);
+        win_load(S, slot, table, neww, lane);
         wave_sync();
-        for (uint32_t i = lane; i < 512; i += 64) S.p16[slot][p16_pos(i)] = (uint16_t)p16_of(S, S.win[slot][i]);
+        p16_rebuild(S, slot, lane);
         ++u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         lds_st(&S.b_seq, u);
@@ -263,11 +261,10 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
 }
 
 template <bool PROF>
-__device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t *__restrict__ fused_g, CmLds &S) {
+__device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
   uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tprev = 0;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  (void)fused_g;
 
   {  // model-independent tables -> LDS (both waves)
     const uint4 *s0 = reinterpret_cast<const uint4 *>(L.tables->stretch + 16384);
@@ -279,11 +276,10 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
     const uint4 *s2 = reinterpret_cast<const uint4 *>(L.tables->dt);
     uint4 *d2 = reinterpret_cast<uint4 *>(S.dt);
     for (uint32_t i = threadIdx.x; i < sizeof(S.dt) / 16; i += 128) d2[i] = s2[i];
-    if (threadIdx.x == 0) { S.cmd_seq = 0; S.cmd_code = 0; S.cmd_ack = 0; S.a_seq = 0; S.b_seq = 0; }
+    if (threadIdx.x == 0) { S.cmd_seq = 0; S.cmd_code = 0; S.cmd_ack = 0; S.t0 = 0; S.b_seq = 0; }
   }
   __syncthreads();                                       // the only workgroup barrier of the kernel
   if (wave == 1) { helper_wave<PROF>(L, S, lane); return; }
-  if (PROF) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); if (lane == 0) S.pad0 = (hw >> 4) & 3; }
   uint32_t cmd_seq = 0;                                  // commands issued to wave B so far
 
   // per-lane constants of the lane <-> table-entry mapping
@@ -291,6 +287,10 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
   const uint32_t lgrp = lane >> 4;                     // 16-lane group
   const uint32_t ltt = 31 - __clz((int)(l15 | 1));     // depth of context j in the nibble tree (0..3)
   const uint32_t lsh_vis = 4 - ltt, lsh_y = 3 - ltt;
+  // LDS offsets of what this lane reads per byte: probability of first-nibble node l15 (+ slot * 32) and the
+  // four second-nibble candidates of quad lgrp (+ slot * 512)
+  const uint32_t p_la = lds_off(&S.p16A[0][0]) + l15 * 2, p_lb = lds_off(&S.p16B[0][0]) + lgrp * 128 + l15 * 8;
+  const uint32_t ring_addr = lds_off(&S.ring[0]), bseq_addr = lds_off(&S.b_seq);
 
   uint8_t *slot_mem = L.arena + (uint64_t)blockIdx.x * L.arena_stride;
 
@@ -309,8 +309,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
     const uint32_t cm_mask = uni(cp->cm_mask);
     const uint32_t limit = (uint32_t)uni(cp->arg[1]) * 4;
     const uint64_t cm_off = uni64(cp->cm_off), cm_bytes = uni64(cp->cm_bytes);
-    const uint32_t kind = uni(M->kind);
-    const uint32_t hk = (kind >> 8) & 255, hshift = (kind >> 16) & 255;
+    const uint32_t hshift = (uni(M->kind) >> 16) & 255;    // HCOMP "a<<= K  *d=a  halt": 9 <= K <= 31 (zh_framing.cpp)
     uint32_t *table = reinterpret_cast<uint32_t *>(slot_mem + cm_off);
 
     // Predictor.init: CM table = 0x80000000 (Predictor.cs:103-104); VM memories zeroed.
@@ -321,20 +320,13 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
       const uint64_t h_off = uni64(M->h_off), tail = uni64(M->arena_bytes) - h_off;
       uint4 *z = reinterpret_cast<uint4 *>(slot_mem + h_off);
       for (uint64_t i = lane; i < tail / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
-      for (uint32_t i = lane; i < 256; i += 64) { S.r[i] = 0; S.pr[i] = 0; }
+      for (uint32_t i = lane; i < 256; i += 64) S.pr[i] = 0;
     }
     wave_sync();
 
-    uint32_t tag = kNoWin;                             // per-lane window directory (lanes >= kWin never match)
-    uint32_t fifo = 0;
-
-    Vm &hz = S.hz;                                     // HCOMP machine (generic form)
-    hz.a = hz.b = hz.c = hz.d = hz.f = 0;
-    hz.prog = L.code + uni(M->code_off) + ZH_CODE_PAD;
-    hz.len = uni(M->hcomp_len);
-    hz.m = slot_mem + uni64(M->m_off); hz.mmask = (uint32_t)((1ull << uni(M->hm)) - 1);
-    hz.h = reinterpret_cast<uint32_t *>(slot_mem + uni64(M->h_off)); hz.hmask = (uint32_t)((1ull << uni(M->hh)) - 1);
-    hz.r = S.r;
+    uint32_t tag = kNoWin;                             // per-lane window directory: lane s = slot s
+    uint32_t lastuse = 0;                              // per-lane: value of t after the last byte / message that used slot s
+    uint32_t t = 0;                                    // bytes decoded + window swaps so far = messages published to wave B
     uint32_t h0 = 0;                                   // h[0] = z.H(0)
 
     int pp_state = 0, pp_hsize = 0;                    // PostProcessor (PostProcessor.cs:12-16)
@@ -377,7 +369,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
       const uint64_t seg_off = uni64(L.segs[si].in_off);
       in_seek(in, seg_off, lane);
 
-      // One decoded byte: Decoder.decompress() (Decoder.cs:32-56) with predict/update folded in.
+      // One decoded byte on wave A alone: Decoder.decompress() (Decoder.cs:32-56) with predict/update folded in.
       // Returns 0..255, -1 at EOS, -2 on error (status set).
       auto decode_byte = [&]() __attribute__((always_inline)) -> int {
         if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
@@ -399,22 +391,28 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
         } else {
           ZH_STAMP(0);
           // ---- probabilities for every context this byte can reach
-          const uint32_t hm = h0 & cm_mask;
-          const uint32_t w = hm >> 9, lo9 = hm & 511, g0 = lo9 >> 4, x = lo9 & 15;
+          const uint32_t w = (h0 & cm_mask) >> 9;
           const uint64_t hit = __ballot(tag == w);
           uint32_t slot;
           if (LIKELY(hit != 0)) slot = (uint32_t)__builtin_ctzll(hit);
-          else slot = win_miss(w, tag, fifo, S, table, lane);
+          else {                                        // swap the window in (wave A alone: nothing is in flight)
+            slot = uni(pick_victim(tag, lastuse, t));
+            const uint32_t old = rdlane(tag, slot);
+            if (old != kNoWin) win_store(S, slot, table, old, lane);
+            win_load(S, slot, table, w, lane);
+            tag = lane == slot ? w : tag;
+            wave_sync();
+          }
+          ++t;
+          lastuse = lane == slot ? t : lastuse;
           ZH_STAMP(1);
-          uint32_t *win = &S.win[slot][0];
-          // lane (g, j) reads position j ^ x of a group: first nibble group g0, second nibble groups (g0^16)^n
-          const uint32_t pos = l15 ^ x;
-          const uint32_t ia = (g0 << 4) | pos;
-          const uint32_t ib0 = ((((g0 ^ 16) & 16) | lgrp) << 4) | pos;   // + 64*k entries for k = 0..3
-          const uint32_t cma = win[ia];
+          // lane j of any quad: first-nibble node j; lane (q, j): node j of second-nibble groups q, q+4, q+8, q+12
+          uint32_t *wa = &S.winA[slot][0], *wb = &S.winB[slot][0];
+          const uint32_t ib0 = (lgrp << 4) | l15;       // + 64*k entries for k = 0..3
+          const uint32_t cma = wa[l15];
           uint32_t cmb[4], pb[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) cmb[k] = win[ib0 + 64 * k];
+          for (int k = 0; k < 4; ++k) cmb[k] = wb[ib0 + 64 * k];
           const uint32_t pa = p16_of(S, cma) << 16;
 #pragma unroll
           for (int k = 0; k < 4; ++k) pb[k] = p16_of(S, cmb[k]) << 16;
@@ -426,7 +424,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
           uint32_t err = 0;
           j = 1;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
+          for (int i = 0; i < 4; ++i) {
             const uint32_t ps = rdlane(pa, j);
             ZH_DEC_STEP(d, ps, j, bad, rn);
             if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane) && !err) err = bad ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF; }
@@ -434,12 +432,12 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
           if (UNLIKELY(err | bad)) { status = err ? -(int)err : ZH_E_CORRUPT; return -2; }
           ZH_STAMP(3);
           const uint32_t n1 = j & 15;
-          // ---- second nibble: group ((g0 ^ n1) & 15) is held by lane group (ga & 3), register ga >> 2
-          const uint32_t ga = uni((g0 ^ n1) & 15), kb = ga >> 2, lb = (ga & 3) * 16;
+          // ---- second nibble: group 16 + n1 is held by quad (n1 & 3), register n1 >> 2
+          const uint32_t ga = uni(n1), kb = ga >> 2, lb = (ga & 3) * 16;
           const uint32_t psel = kb == 0 ? pb[0] : kb == 1 ? pb[1] : kb == 2 ? pb[2] : pb[3];
           uint32_t j2 = 1;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
+          for (int i = 0; i < 4; ++i) {
             const uint32_t ps = rdlane(psel, lb + j2);
             ZH_DEC_STEP(d, ps, j2, bad, rn);
             if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane) && !err) err = bad ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF; }
@@ -450,48 +448,38 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
           c = (int)(n1 << 4 | n2);
 
           // ---- train the 8 visited entries (Predictor.train), one pass over the lanes:
-          // lane group (ga&3) updates the second-nibble entries, group (ga&3)^1 the first-nibble ones.
+          // quad (n1 & 3) updates the second-nibble entries, quad (n1 & 3) ^ 1 the first-nibble ones.
           {
             const bool isb = lgrp == (ga & 3);
             const bool isa = lgrp == ((ga & 3) ^ 1);
             const uint32_t cmsel = kb == 0 ? cmb[0] : kb == 1 ? cmb[1] : kb == 2 ? cmb[2] : cmb[3];
             const uint32_t cm = isb ? cmsel : cma;
-            const uint32_t idx = isb ? ib0 + 64 * kb : ia;
             const uint32_t nib = isb ? n2 : n1;
             const bool vis = (isa || isb) && l15 != 0 && l15 == ((16 | nib) >> lsh_vis);
             const uint32_t yy = (nib >> lsh_y) & 1;
             const uint32_t cnt = cm & 0x3ff;
-            const int err = (int)(yy * 32767) - (int)(cm >> 17);
-            const uint32_t nv = cm + (((uint32_t)err * (uint32_t)S.dt[cnt]) & 0xFFFFFC00u) + (cnt < limit);
-            if (vis) win[idx] = nv;
+            const int e = (int)(yy * 32767) - (int)(cm >> 17);
+            const uint32_t nv = cm + (((uint32_t)e * (uint32_t)S.dt[cnt]) & 0xFFFFFC00u) + (cnt < limit);
+            if (vis) { if (isb) wb[ib0 + 64 * kb] = nv; else wa[l15] = nv; }
           }
           ZH_STAMP(5);
-
-          // ---- HCOMP (Predictor.cs:464-470): h[0] = H(0) after z.run(c)
-          if (LIKELY(hk == ZH_HK_SHIFT)) h0 = (uint32_t)c << hshift;     // "a<<= K  *d=a  halt"
-          else {
-            int rc = (int)uni((uint32_t)vm_run(hz, (uint32_t)c, nullptr, L.budget));
-            if (rc) { status = rc; return -2; }
-            h0 = uni(hz.h[0]);
-          }
+          h0 = (uint32_t)c << hshift;                    // HCOMP "a<<= K  *d=a  halt" (Predictor.cs:464-470)
         }
-
         return (int)uni((uint32_t)c);
       };
 
       for (;;) {
-        if (LIKELY(pp_state == 1 && hk == ZH_HK_SHIFT)) {
-          // ---- steady state: PASS post-processor (PostProcessor.cs:49-51) and the recognised HCOMP.
-          // ===== two-wave steady state =====
+        if (LIKELY(pp_state == 1)) {
+          // ===== steady state: PASS post-processor (PostProcessor.cs:49-51), two wavefronts =====
           // hand the window cache and the output to wave B
           S.tags[lane] = tag;
-          if (lane < kRing) S.ring[lane] = 0xFFFFFFFFu;   // tag 127: never the tag of messages 0..15
+          if (lane < kRing) S.ring[lane] = ((ring_tag(t) + 64) & 127) << 25;   // never the tag of messages t .. t+15
           out_flush(ob, lane);
           if (lane == 0) {
             S.table = (uint64_t)(reinterpret_cast<uint8_t *>(table) - L.arena); S.limit = limit;
             S.ob_base = (uint64_t)(ob.base - L.out); S.ob_cap = ob.cap; S.ob_len = ob.len; S.ob_stored = ob.stored;
             S.ob_word = ob.word; S.ob_room = ob.room;
-            S.a_seq = 0; S.b_seq = 0; S.cmd_code = kCmdEnter;
+            S.t0 = t; S.b_seq = t; S.cmd_code = kCmdEnter;
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           ++cmd_seq;
@@ -503,13 +491,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
           }
           if (!helper_ok) { status = ZH_E_HELPER; break; }
-          // Pin every loop-carried scalar to the scalar unit, so that LLVM's uniformity analysis sees a
-          // loop whose state is uniform on entry and on the back edge.
-          d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr);
-          in.cbase = uni64(in.cbase); in.k = uni(in.k); in.avail = uni(in.avail);
-          h0 = uni(h0); fifo = uni(fifo);
-          uint32_t t = 0, b_done = 0;                     // messages published / known completed
-          uint32_t lastuse = 0;                           // lane s: message count after the last one touching window slot s
+          uint32_t b_done = t;                            // messages known completed by wave B
           auto publish = [&](uint32_t m0) __attribute__((always_inline)) {
             lds_order();
             lds_put0(&S.ring[t & (kRing - 1)], ring_tag(t) << 25 | m0);
@@ -528,16 +510,11 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
           // state it has, commits nothing, and forces that test; the common path carries no exit bookkeeping.
           enum : uint32_t { kEvEos = 1, kEvCorrupt, kEvEof, kEvHelper };
           uint32_t ev = 0;
-          const uint32_t p16_base = (uint32_t)(uintptr_t)&S.p16[0][0];
-          const uint32_t lane_b = p16_base + lgrp * 128;  // second-nibble quad of this lane inside a half window
           uint32_t tq;
-          // hand-written loop for the common case (zh_cm_fast.h); the C++ body below is the same
-          // algorithm and takes every byte the fast loop declines
-          const bool fast_ok = hshift >= 9 && hshift < 32;
-          const uint32_t fast_la = p16_base + (l15 << 3), fast_lb = p16_base + 512 + lgrp * 128 + (l15 << 3);
-          const uint32_t fast_ring = (uint32_t)(uintptr_t)&S.ring[0], fast_bsa = (uint32_t)(uintptr_t)&S.b_seq;
           for (;;) {
-            if (fast_ok) {
+            // hand-written loop for the common case (zh_cm_fast.h); the C++ body below is the same
+            // algorithm and takes every byte the fast loop declines
+            {
               if (in.avail - in.k < 40 && in.avail == 256) in_seek(in, in_pos(in), lane);   // re-centre the chunk
               uint32_t code;
               d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr); in.k = uni(in.k); in.avail = uni(in.avail);
@@ -546,7 +523,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
               const uint32_t t_in = t;
               if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(f0)::"memory"); }
               ZH_CM_FAST_LOOP(d.low, d.high, d.curr, in.k, t, h0, b_done, lastuse, code, in.avail, uni(cm_mask), uni(hshift),
-                              uni(fast_ring), fast_bsa, in.cur, tag, lane, fast_la, fast_lb);
+                              uni(ring_addr), bseq_addr, in.cur, tag, lane, p_la, p_lb);
               if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(f1)::"memory"); prof[2] += f1 - f0; prof[3] += t - t_in; }
               if (UNLIKELY(code)) { ev = kEvCorrupt; d.low = d.high = d.curr = 1; }   // the EOS test below ends the section
             }
@@ -566,14 +543,12 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
               if (dec_renorm_chk(d, in, lane, bad)) err = kEvEof;
             }
             ZH_STAMP(0);
-            const uint32_t hm = h0 & cm_mask;
-            const uint32_t w = hm >> 9, lo9 = hm & 511, g0 = lo9 >> 4, x = lo9 & 15;
+            const uint32_t w = (h0 & cm_mask) >> 9;
             const uint64_t hit = __ballot(tag == w);
             uint32_t slot;
             if (LIKELY(hit != 0)) slot = (uint32_t)__builtin_ctzll(hit);
             else {                                        // window miss: wave B swaps the window
-              slot = fifo;
-              fifo = fifo + 1 == (uint32_t)kWin ? 0 : fifo + 1;
+              slot = uni(pick_victim(tag, lastuse, t));
               const uint32_t old = rdlane(tag, slot);
               tag = lane == slot ? w : tag;
               if (lane == 0) { uint32_t *q = S.aux[t & (kRing - 1)]; q[0] = w; q[1] = old; }
@@ -588,14 +563,8 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
               if (UNLIKELY(t - b_done > back)) { if (!wait_done(t - back)) helper_lost = 1; }
             }
             ZH_STAMP(1);
-            // p16 storage order inside a window (p16_pos): the four second-nibble entries a lane needs
-            // are one 8-byte read, the first-nibble entry one 2-byte read.
-            const uint32_t pos8 = (l15 ^ x) << 3;
-            const uint32_t s_win = slot << 10;
-            const uint32_t s_a = s_win + ((g0 >> 4) << 9) + ((g0 & 3) << 7) + (((g0 >> 2) & 3) << 1);
-            const uint32_t s_b = s_win + (((g0 >> 4) ^ 1) << 9);
-            const uint32_t pa = (uint32_t)lds_u16(p16_base + s_a + pos8) << 16;
-            const uint64_t pb = lds_u64(lane_b + s_b + pos8);
+            const uint32_t pa = (uint32_t)lds_u16(p_la + slot * 32) << 16;
+            const uint64_t pb = lds_u64(p_lb + slot * 512);
             uint32_t j = 1;
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
@@ -607,8 +576,8 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
                 if (dec_renorm_chk(d, in, lane, bad) && !err) err = was ? kEvCorrupt : kEvEof;
               }
             }
-            // second nibble: group (g0 ^ n1) & 15 of the other half = quad (ga & 3), element ga >> 2
-            const uint32_t ga = uni((g0 ^ j) & 15), lb = (ga & 3) * 16;
+            // second nibble: group 16 + n1 = quad (n1 & 3), element n1 >> 2
+            const uint32_t ga = uni(j & 15), lb = (ga & 3) * 16;
             const uint32_t psel = (uint32_t)(pb >> ((ga >> 2) * 16)) << 16;
             uint32_t j2 = 1;
 #pragma unroll
@@ -627,7 +596,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
             if (LIKELY((err | bad | helper_lost) == 0)) {
               const uint32_t cc = (j << 4) + j2 - 272;     // j = 16 | n1, j2 = 16 | n2
               // the byte goes to wave B: training, probability refresh and output happen there
-              publish(kMsgByte << 23 | cc << 15 | lo9 << 6 | slot);
+              publish(kMsgByte << 23 | cc << 15 | slot);
               lastuse = lane == slot ? t : lastuse;
               h0 = cc << hshift;                           // HCOMP "a<<= K  *d=a  halt" (Predictor.cs:464-470)
             } else {
@@ -638,29 +607,24 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
             ZH_STAMP(6);
           }
           if (!ev) ev = tq ? kEvCorrupt : kEvEos;
-          int c = -2;
           if (ev == kEvEos) {                             // y = 1: high = mid = low, then the usual renormalisation
             d.high = d.low;
             if (dec_renorm(d, in, lane)) status = ZH_E_EOF;
             else if (d.curr != 0) status = ZH_E_EOS;
-            else c = -1;
           } else {
             status = ev == kEvCorrupt ? ZH_E_CORRUPT : ev == kEvEof ? ZH_E_EOF : ZH_E_HELPER;
           }
-          (void)c;
           // leave the section: B flushes the output and hands its state back
           publish(kMsgLeave << 23);
           if (!wait_done(t) && !status) status = ZH_E_HELPER;
           ob.len = uni64(S.ob_len); ob.stored = uni64(S.ob_stored); ob.word = uni(S.ob_word); ob.room = uni(S.ob_room);
           ob.park = 0;
-          break;                                          // EOS (c == -1) or error (c == -2)
+          break;                                          // end of segment or error
         }
         int c = decode_byte();
         if (c == -2) break;
         // ---- PostProcessor.write(c) (PostProcessor.cs:37-86)
-        if (pp_state == 1) {
-          if (c >= 0) out_put(ob, (uint32_t)c, lane);
-        } else if (pp_state == 5) {
+        if (pp_state == 5) {
           // every lane runs the program (same inputs, same stores): keeps control flow wave-uniform
           int rc = (int)uni((uint32_t)vm_run(pz, (uint32_t)c, &sink, L.budget));
           if (rc) { status = rc; break; }
@@ -712,22 +676,22 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, const uint16_t
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(128) void zh_decode_cm(ZhLaunch L, const uint16_t *__restrict__ fused_g) {
+extern "C" __global__ __launch_bounds__(128) void zh_decode_cm(ZhLaunch L) {
   __shared__ CmLds S;
-  decode_cm_body<false>(L, fused_g, S);
+  decode_cm_body<false>(L, S);
 }
 
-extern "C" __global__ __launch_bounds__(128) void zh_decode_cm_prof(ZhLaunch L, const uint16_t *__restrict__ fused_g) {
+extern "C" __global__ __launch_bounds__(128) void zh_decode_cm_prof(ZhLaunch L) {
   __shared__ CmLds S;
-  decode_cm_body<true>(L, fused_g, S);
+  decode_cm_body<true>(L, S);
 }
 
-extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL(zh_decode_cm_prof, dim3(grid), dim3(128), 0, stream, *L, fused);
+extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, const uint16_t *, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL(zh_decode_cm_prof, dim3(grid), dim3(128), 0, stream, *L);
   return hipGetLastError();
 }
 
-extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL(zh_decode_cm, dim3(grid), dim3(128), 0, stream, *L, fused);
+extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, const uint16_t *, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL(zh_decode_cm, dim3(grid), dim3(128), 0, stream, *L);
   return hipGetLastError();
 }

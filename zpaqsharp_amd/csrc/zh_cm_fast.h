@@ -101,9 +101,10 @@
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
   "s_add_u32 %[low], %[low], 1\n\t"                                   \
   /* cached probabilities: lane j <- node j of the first nibble; lane (q, j) <- node j of groups q, q+4, q+8, q+12 */ \
-  "s_lshl_b32 s80, s82, 10\n\t"                                       \
+  "s_lshl_b32 s80, s82, 5\n\t"                                        \
+  "s_lshl_b32 s84, s82, 9\n\t"                                        \
   "v_add_u32_e32 v252, s80, %[la]\n\t"                                \
-  "v_add_u32_e32 v250, s80, %[lb]\n\t"                                \
+  "v_add_u32_e32 v250, s84, %[lb]\n\t"                                \
   "ds_read_u16 v252, v252\n\t"                                        \
   "ds_read_b64 v[250:251], v250\n\t"                                  \
   "s_mov_b32 s93, 0\n\t"                                              \

@@ -383,11 +383,13 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
     m.kind += zh_spec_lookup(hdr, len);                                  // ZH_FAM_CHAIN + {0 none, 1 min, 2 mid, 3 max}
     m.kind |= zh_native_lookup(hdr + cp, m.hcomp_len) << 8;              // native HCOMP id or 0
   }
+  // Single direct CM whose HCOMP is "a<<= K  *d=a  halt" (D is 0 at every entry) with K >= 9: the low 9 bits of the
+  // context hash are zero, which is what zh_cm.hip's compact window cache relies on.  Other single-CM models keep
+  // the family chosen above.
   if (m.n == 1 && m.comp[0].type == ZH_CM && m.comp[0].arg[0] >= 9) {
-    m.kind = ZH_FAM_CM1;
-    const uint8_t *hc = hdr + cp;                       // "a<<= K  *d=a  halt" (D is 0 at every entry)
-    if (m.hcomp_len == 5 && hc[0] == 207 && hc[2] == 112 && hc[3] == 56 && hc[4] == 0)
-      m.kind |= ZH_HK_SHIFT << 8 | (uint32_t)(hc[1] & 31) << 16;
+    const uint8_t *hc = hdr + cp;
+    if (m.hcomp_len == 5 && hc[0] == 207 && hc[2] == 112 && hc[3] == 56 && hc[4] == 0 && (hc[1] & 31) >= 9)
+      m.kind = ZH_FAM_CM1 | ZH_HK_SHIFT << 8 | (uint32_t)(hc[1] & 31) << 16;
   }
   return ZPAQHIP_OK;
 }
