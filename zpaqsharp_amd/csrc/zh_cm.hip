@@ -537,24 +537,25 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
             // ---- EOS flag, p = 0 (Decoder.cs:136-158 with mid = low): y = (curr <= low)
             tq = d.curr - d.low;
             if (UNLIKELY(tq - 1 >= d.high - d.low)) break;   // tq == 0: y = 1;  tq > high - low: "archive corrupted"
+            // ---- the byte's window (before any coder state changes, so that a miss can simply start over)
+            const uint32_t w = (h0 & cm_mask) >> 9;
+            const uint64_t hit = __ballot(tag == w);
+            if (UNLIKELY(hit == 0)) {                     // window miss: wave B swaps the window in
+              const uint32_t vs = uni(pick_victim(tag, lastuse, t));
+              const uint32_t old = rdlane(tag, vs);
+              tag = lane == vs ? w : tag;
+              if (lane == 0) { uint32_t *q = S.aux[t & (kRing - 1)]; q[0] = w; q[1] = old; }
+              publish(kMsgMiss << 23 | vs);
+              lastuse = lane == vs ? t : lastuse;
+              continue;                                   // the fast loop waits for B and takes the byte
+            }
+            const uint32_t slot = (uint32_t)__builtin_ctzll(hit);
             uint32_t bad = 0, err = 0, helper_lost = 0;
             d.low += 1;
             if (UNLIKELY((d.high ^ d.low) < 0x1000000u)) {
               if (dec_renorm_chk(d, in, lane, bad)) err = kEvEof;
             }
             ZH_STAMP(0);
-            const uint32_t w = (h0 & cm_mask) >> 9;
-            const uint64_t hit = __ballot(tag == w);
-            uint32_t slot;
-            if (LIKELY(hit != 0)) slot = (uint32_t)__builtin_ctzll(hit);
-            else {                                        // window miss: wave B swaps the window
-              slot = uni(pick_victim(tag, lastuse, t));
-              const uint32_t old = rdlane(tag, slot);
-              tag = lane == slot ? w : tag;
-              if (lane == 0) { uint32_t *q = S.aux[t & (kRing - 1)]; q[0] = w; q[1] = old; }
-              publish(kMsgMiss << 23 | slot);
-              lastuse = lane == slot ? t : lastuse;
-            }
             // The cached probabilities of this window must include every earlier byte that used it, and
             // the ring must not overrun: B may be at most `back` messages behind.
             {
