@@ -71,6 +71,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--gen-threads", type=int, default=None)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; the real thing) | gloo (rehearsal of the N>1 path)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: ranks share the visible GPUs round-robin (needs --dist-backend gloo)")
     return ap.parse_args()
 
 
@@ -91,11 +94,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ZPAQ decode path has no CPU fallback")
+    if args.share_gpu:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if args.dist_backend == "nccl" else None     # gloo moves CPU tensors
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     model_name = args.model
     base = model_name.split("+")[0]
@@ -126,7 +135,7 @@ def main():
     weights = np.array([sc.segments[b.first_seg].data_len for b in sc.blocks], dtype=np.int64)
     if world > 1:
         from zpaqsharp_amd import multigpu
-        all_w = multigpu.all_gather_table(weights, dist, dev)
+        all_w = multigpu.all_gather_table(weights, dist, coll_dev)
         assert all_w.shape == (world, nb)
 
     def step():
@@ -150,7 +159,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev or "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = ctx.stats()
@@ -167,7 +176,7 @@ def main():
     okv = np.array([int(ok), plain_bytes, coded_bytes], dtype=np.int64)
     if world > 1:
         from zpaqsharp_amd import multigpu
-        allv = multigpu.all_gather_table(okv, dist, dev)
+        allv = multigpu.all_gather_table(okv, dist, coll_dev)
         ok = bool(allv[:, 0].all())
         total_plain = int(allv[:, 1].sum())
     else:
