@@ -76,9 +76,6 @@
 #define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, avail_, mask_, hs_, ring_, bsa_, cur_, tag_, lid_, la_, lb_) \
   asm volatile(                                                       \
   ".Lzh_byte_%=:\n\t"                                                 \
-  "s_sub_u32 s80, %[avail], %[k]\n\t"                                 \
-  "s_cmp_lt_u32 s80, 40\n\t"                                          \
-  "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
   /* window lookup: lane s of `tag` holds the window id cached in slot s */ \
   "s_and_b32 s81, %[h0], %[mask]\n\t"                                 \
   "s_lshr_b32 s81, s81, 9\n\t"                                        \
@@ -93,6 +90,17 @@
   "s_cmp_gt_u32 s89, s83\n\t"                                         \
   "s_cbranch_scc1 .Lzh_fresh_%=\n"                                    \
   ".Lzh_ok_%=:\n\t"                                                   \
+  /* cached probabilities: lane j <- node j of the first nibble; lane (q, j) <- node j of groups q, q+4, q+8, q+12. */ \
+  /* Issued before the remaining tests so that their latency is covered; a slow exit waits for them. */ \
+  "s_lshl_b32 s80, s82, 5\n\t"                                        \
+  "s_lshl_b32 s84, s82, 9\n\t"                                        \
+  "v_add_u32_e32 v252, s80, %[la]\n\t"                                \
+  "v_add_u32_e32 v250, s84, %[lb]\n\t"                                \
+  "ds_read_u16 v252, v252\n\t"                                        \
+  "ds_read_b64 v[250:251], v250\n\t"                                  \
+  "s_sub_u32 s80, %[avail], %[k]\n\t"                                 \
+  "s_cmp_lt_u32 s80, 40\n\t"                                          \
+  "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
   /* EOS flag (p = 0): y = curr <= low; leave when y = 1 or curr is out of range */ \
   "s_sub_u32 s80, %[curr], %[low]\n\t"                                \
   "s_sub_u32 s84, %[high], %[low]\n\t"                                \
@@ -100,13 +108,6 @@
   "s_cmp_ge_u32 s80, s84\n\t"                                         \
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
   "s_add_u32 %[low], %[low], 1\n\t"                                   \
-  /* cached probabilities: lane j <- node j of the first nibble; lane (q, j) <- node j of groups q, q+4, q+8, q+12 */ \
-  "s_lshl_b32 s80, s82, 5\n\t"                                        \
-  "s_lshl_b32 s84, s82, 9\n\t"                                        \
-  "v_add_u32_e32 v252, s80, %[la]\n\t"                                \
-  "v_add_u32_e32 v250, s84, %[lb]\n\t"                                \
-  "ds_read_u16 v252, v252\n\t"                                        \
-  "ds_read_b64 v[250:251], v250\n\t"                                  \
   "s_mov_b32 s93, 0\n\t"                                              \
   "s_mov_b32 s90, 1\n\t"                                              \
   "s_xor_b32 s84, %[high], %[low]\n\t"                                \
@@ -188,6 +189,7 @@
   "s_mov_b32 %[code], 1\n\t"                                          \
   "s_branch .Lzh_end_%=\n"                                            \
   ".Lzh_slow_%=:\n\t"                                                 \
+  "s_waitcnt lgkmcnt(0)\n\t"                                          \
   "s_mov_b32 %[code], 0\n"                                            \
   ".Lzh_end_%=:\n\t"                                                  \
   : [low] "+s"(low_), [high] "+s"(high_), [curr] "+s"(curr_), [k] "+s"(k_), [t] "+s"(t_), [h0] "+s"(h0_), \
