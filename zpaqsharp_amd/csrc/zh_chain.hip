@@ -222,7 +222,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
     // mixers (wave-uniform table in LDS) and which of them each lane feeds
     uint32_t nmix = 0;
     uint32_t mx_lane[kMaxMix] = {0, 0, 0, 0}, mx_j0[kMaxMix] = {0, 0, 0, 0}, mx_m[kMaxMix] = {0, 0, 0, 0}, mx_lv[kMaxMix] = {0, 0, 0, 0};
-    uint32_t *mx_cm[kMaxMix] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t mx_off[kMaxMix] = {0, 0, 0, 0};            // arena offsets of the mixer tables (pointers formed at use stay GLOBAL)
     {
       const uint64_t mm = __ballot(me.type == ZH_MIX);
 #pragma unroll
@@ -232,7 +232,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
         if (!rest) break;
         const uint32_t ml = (uint32_t)__builtin_ctzll(rest);
         mx_lane[q] = ml; mx_j0[q] = rdlane(me.a1, ml); mx_m[q] = rdlane(me.a2, ml); mx_lv[q] = rdlane(me.level, ml);
-        mx_cm[q] = reinterpret_cast<uint32_t *>(slot_mem + rdlane(me.cmo, ml));
+        mx_off[q] = rdlane(me.cmo, ml);
         if (lane >= mx_j0[q] && lane < mx_j0[q] + mx_m[q]) me.memb |= 1u << q;
         nmix = (uint32_t)q + 1;
       }
@@ -404,16 +404,23 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
               if (q >= (kSpec ? SP::nmix : nmix)) break;
               const uint32_t rowv = ((me.h + (c8 & me.a4)) & (me.c - 1)) * mx_m[q];    // valid in the mixer lane
               rows[q] = rdlane(rowv, mx_lane[q]);
-              if (me.memb >> q & 1) me.mw[q] = (int)mx_cm[q][rows[q] + (lane - mx_j0[q])];
+              if (me.memb >> q & 1) me.mw[q] = (int)reinterpret_cast<const uint32_t *>(slot_mem + mx_off[q])[rows[q] + (lane - mx_j0[q])];
             }
+            // Everything update() will need from LDS is fetched here, before the bit is decoded: the entry
+            // itself (pv), its adaptation rate (pdt) and BOTH successor states (pns); update() is then
+            // register arithmetic and stores only.
+            uint32_t pv = 0, pns = 0;
+            int pdt = 0;
             if (ZH_HAS(ZH_CM) && me.type == ZH_CM) {
               me.cxt = (me.h ^ hmap4) & 15;
-              const uint32_t v = reinterpret_cast<const uint32_t *>(myslot)[me.cxt];
-              me.p = S.t.stretch[v >> 17];
+              pv = reinterpret_cast<const uint32_t *>(myslot)[me.cxt];
+              me.p = S.t.stretch[pv >> 17];
+              pdt = S.t.dt[pv & 0x3ff];
             }
             if ((ZH_HAS(ZH_ICM) || ZH_HAS(ZH_ISSE)) && (me.type == ZH_ICM || me.type == ZH_ISSE)) {
               me.cxt = myslot[hm15];                     // the bit history of this context
-              if (me.type == ZH_ICM) me.p = S.t.stretch[S.small[me.sbase + me.cxt] >> 8];
+              pns = *reinterpret_cast<const uint16_t *>(&S.t.ns[me.cxt * 4]);   // next(state, 0) | next(state, 1) << 8
+              if (me.type == ZH_ICM) { pv = S.small[me.sbase + me.cxt]; me.p = S.t.stretch[pv >> 8]; }
               else {
                 const uint2 w = *reinterpret_cast<const uint2 *>(&S.small[me.sbase + me.cxt * 2]);
                 me.w0 = (int)w.x; me.w1 = (int)w.y;
@@ -510,7 +517,8 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             }
             ZH_STAMP(1);
             // ================= decode the bit =================
-            const uint32_t pr = rdlane((uint32_t)S.t.squash[me.p + 2048], n - 1);
+            const int sqp = (int)S.t.squash[me.p + 2048];          // squash(p[i]) of every lane, one LDS pass
+            const uint32_t pr = rdlane((uint32_t)sqp, n - 1);
             const uint32_t ps = (pr * 2 + 1) << 16;
             ZH_DEC_STEP(d, ps, j, bad, rn);
             if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane) && !err) err = bad ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF; }
@@ -518,7 +526,6 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
 
             ZH_STAMP(2);
             // ================= update (Predictor.cs:363-461) =================
-            const int sqp = (int)S.t.squash[me.p + 2048];          // squash(p[i]) of every lane, one LDS pass
             const int emix = (y * 32767 - sqp) * (int)me.a3 >> 4;   // MIX error term (meaningful in mixer lanes)
 #pragma unroll
             for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {      // MIX: error from the mixer lane, weights in the input lanes
@@ -526,14 +533,13 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
               const int eq = (int)rdlane((uint32_t)emix, mx_lane[q]);
               if (me.memb >> q & 1) {
                 me.mw[q] = clamp512k(me.mw[q] + ((eq * me.p + (1 << 12)) >> 13));
-                mx_cm[q][rows[q] + (lane - mx_j0[q])] = (uint32_t)me.mw[q];
+                reinterpret_cast<uint32_t *>(slot_mem + mx_off[q])[rows[q] + (lane - mx_j0[q])] = (uint32_t)me.mw[q];
               }
             }
             if (ZH_HAS(ZH_CM) && me.type == ZH_CM) {
-              uint32_t *pn = &reinterpret_cast<uint32_t *>(myslot)[me.cxt];
-              const uint32_t v = *pn, cnt = v & 0x3ff;
-              const int e = y * 32767 - (int)(v >> 17);
-              *pn = v + (((uint32_t)e * (uint32_t)S.t.dt[cnt]) & 0xFFFFFC00u) + (cnt < me.limit);
+              const uint32_t cnt = pv & 0x3ff;
+              const int e = y * 32767 - (int)(pv >> 17);
+              reinterpret_cast<uint32_t *>(myslot)[me.cxt] = pv + (((uint32_t)e * (uint32_t)pdt) & 0xFFFFFC00u) + (cnt < me.limit);
             }
             if (ZH_HAS(ZH_SSE) && me.type == ZH_SSE) {
               const uint32_t v = (uint32_t)me.w0, cnt = v & 0x3ff;
@@ -542,10 +548,9 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
                   v + (((uint32_t)e * (uint32_t)S.t.dt[cnt]) & 0xFFFFFC00u) + (cnt < me.limit);
             }
             if ((ZH_HAS(ZH_ICM) || ZH_HAS(ZH_ISSE)) && (me.type == ZH_ICM || me.type == ZH_ISSE)) {
-              myslot[hm15] = S.t.ns[me.cxt * 4 + y];      // next bit-history state (StateTable.next)
+              myslot[hm15] = (uint8_t)(pns >> (y * 8));   // next bit-history state (StateTable.next)
               if (me.type == ZH_ICM) {
-                uint32_t *pn = &S.small[me.sbase + me.cxt];
-                *pn += (uint32_t)((int)(y * 32767 - (int)(*pn >> 8)) >> 2);
+                S.small[me.sbase + me.cxt] = pv + (uint32_t)((int)(y * 32767 - (int)(pv >> 8)) >> 2);
               } else {
                 const int e = y * 32767 - sqp;
                 uint2 w;
