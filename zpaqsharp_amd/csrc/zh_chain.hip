@@ -48,6 +48,7 @@ struct alignas(16) ChainLds {
   ZhTables t;
   uint32_t small[kSmallWords];
   uint8_t slot[64][64];                   // per-lane nibble cache (hash row or CM line)
+  uint32_t dummy[64];                     // per-lane sink for the stores of lanes a branch-free step does not concern
   uint32_t hreg[kHWords];
   uint8_t mreg[kMBytes];
   uint32_t r[256], pr[256];
@@ -60,6 +61,12 @@ struct alignas(16) ChainLds {
 static_assert(sizeof(ChainLds) <= 163840, "LDS budget");
 
 __device__ __forceinline__ int clampk(int x, int lo, int hi) { return x < lo ? lo : x > hi ? hi : x; }
+// Typed LDS accesses by LDS byte offset: lets one ds_* instruction serve lanes of different component types
+// (the address is selected per lane) instead of one divergent branch per type.
+typedef __attribute__((address_space(3))) uint8_t *lds_u8_p;
+typedef __attribute__((address_space(3))) uint16_t *lds_u16_p;
+typedef __attribute__((address_space(3))) uint32_t *lds_u32_p;
+__device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(uintptr_t)p; }
 
 // Per-lane view of one component (Component.cs:18-57 + its header arguments).
 struct ZhSpec_generic {                    // run-time everything (any header the host accepts for this family)
@@ -262,6 +269,13 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
     }
     __syncthreads();
 
+    // per-lane constants of the branch-free ICM / ISSE steps
+    const bool is_icm = me.type == ZH_ICM, is_isse = me.type == ZH_ISSE, is_ii = is_icm || is_isse, is_match = me.type == ZH_MATCH;
+    const uint32_t ii_tab = lds_off(&S.small[0]) + me.sbase * 4;      // table of this lane (others: the pool's start, read only)
+    const uint32_t ii_sh = is_isse ? 3u : 2u;                         // 8-byte weight pairs / 4-byte probabilities
+    const uint32_t slot_off = lds_off(myslot), dummy_off = lds_off(&S.dummy[lane]), ns_off = lds_off(&S.t.ns[0]);
+    int pm0 = 0, pm1 = 0;                                             // MATCH: stretch of +-dt2k[len] for this byte
+
     // HCOMP machine (ZPAQL.cs:1010-1026): H and M in LDS when they fit
     Vm &hz = S.hz;
     hz.a = hz.b = hz.c = hz.d = hz.f = 0;
@@ -417,21 +431,22 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
               me.p = S.t.stretch[pv >> 17];
               pdt = S.t.dt[pv & 0x3ff];
             }
-            if ((ZH_HAS(ZH_ICM) || ZH_HAS(ZH_ISSE)) && (me.type == ZH_ICM || me.type == ZH_ISSE)) {
-              me.cxt = myslot[hm15];                     // the bit history of this context
-              pns = *reinterpret_cast<const uint16_t *>(&S.t.ns[me.cxt * 4]);   // next(state, 0) | next(state, 1) << 8
-              if (me.type == ZH_ICM) { pv = S.small[me.sbase + me.cxt]; me.p = S.t.stretch[pv >> 8]; }
-              else {
-                const uint2 w = *reinterpret_cast<const uint2 *>(&S.small[me.sbase + me.cxt * 2]);
-                me.w0 = (int)w.x; me.w1 = (int)w.y;
-              }
+            uint32_t ii_a = 0;
+            if (ZH_HAS(ZH_ICM) || ZH_HAS(ZH_ISSE)) {
+              // every lane walks the same three dependent LDS reads (row byte -> table entry -> stretch);
+              // lanes of other types read harmless locations and keep nothing
+              const uint32_t sw = *(lds_u32_p)(slot_off + (hm15 & 12));
+              const uint32_t st = (sw >> ((hm15 & 3) * 8)) & 255;               // the bit history of this context
+              ii_a = ii_tab + (st << ii_sh);
+              const uint32_t w_x = *(lds_u32_p)ii_a, w_y = *(lds_u32_p)(ii_a + 4);
+              const uint32_t nsv = *(lds_u16_p)(ns_off + st * 4);               // next(state, 0) | next(state, 1) << 8
+              const int stv = S.t.stretch[is_icm ? w_x >> 8 : 0];
+              if (is_ii) { me.cxt = st; pns = nsv; pv = w_x; me.w0 = (int)w_x; me.w1 = (int)w_y; }
+              if (is_icm) me.p = stv;
             }
-            if (ZH_HAS(ZH_MATCH) && me.type == ZH_MATCH) {
-              if (me.a == 0) me.p = 0;
-              else {
-                me.c = (me.mbyte >> (7 - me.cxt)) & 1;
-                me.p = S.t.stretch[(S.t.dt2k[me.a] * (1 - 2 * (int)me.c)) & 32767];
-              }
+            if (ZH_HAS(ZH_MATCH)) {
+              const uint32_t cbit = (me.mbyte >> (7 - (me.cxt & 7))) & 1;
+              if (is_match) { me.c = me.a ? cbit : me.c; me.p = me.a ? (cbit ? pm1 : pm0) : 0; }
             }
             if (ZH_HAS(ZH_MIX2) && me.type == ZH_MIX2) {
               me.cxt = (me.h + (c8 & me.a4)) & (me.c - 1);
@@ -547,17 +562,14 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
               reinterpret_cast<uint32_t *>(slot_mem + me.cmo)[me.cxt & me.cm_mask] =
                   v + (((uint32_t)e * (uint32_t)S.t.dt[cnt]) & 0xFFFFFC00u) + (cnt < me.limit);
             }
-            if ((ZH_HAS(ZH_ICM) || ZH_HAS(ZH_ISSE)) && (me.type == ZH_ICM || me.type == ZH_ISSE)) {
-              myslot[hm15] = (uint8_t)(pns >> (y * 8));   // next bit-history state (StateTable.next)
-              if (me.type == ZH_ICM) {
-                S.small[me.sbase + me.cxt] = pv + (uint32_t)((int)(y * 32767 - (int)(pv >> 8)) >> 2);
-              } else {
-                const int e = y * 32767 - sqp;
-                uint2 w;
-                w.x = (uint32_t)clamp512k(me.w0 + ((e * me.pj + (1 << 12)) >> 13));
-                w.y = (uint32_t)clamp512k(me.w1 + ((e + 16) >> 5));
-                *reinterpret_cast<uint2 *>(&S.small[me.sbase + me.cxt * 2]) = w;
-              }
+            if (ZH_HAS(ZH_ICM) || ZH_HAS(ZH_ISSE)) {            // all lanes, stores of unconcerned lanes go to their dummy cell
+              *(lds_u8_p)(is_ii ? slot_off + hm15 : dummy_off) = (uint8_t)(pns >> (y * 8));   // StateTable.next
+              const int e = y * 32767 - sqp;
+              const uint32_t n0 = is_icm ? pv + (uint32_t)((int)(y * 32767 - (int)(pv >> 8)) >> 2)
+                                         : (uint32_t)clamp512k(me.w0 + ((e * me.pj + (1 << 12)) >> 13));
+              const uint32_t n1 = (uint32_t)clamp512k(me.w1 + ((e + 16) >> 5));
+              *(lds_u32_p)(is_ii ? ii_a : dummy_off) = n0;
+              *(lds_u32_p)(is_isse ? ii_a + 4 : dummy_off) = n1;
             }
             if (ZH_HAS(ZH_MATCH) && me.type == ZH_MATCH) {
               if ((int)me.c != y) me.a = 0;
@@ -638,6 +650,11 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
               if (lane == ml) me.a = len > 255 ? 255 : len;
             }
             if (ism) me.mbyte = (slot_mem + me.hto)[(me.limit - me.b) & me.ht_mask];
+            if (ZH_HAS(ZH_MATCH)) {                        // the two predictions a match of this length can make (Predictor.cs:273-287)
+              const int dk = S.t.dt2k[is_match ? me.a : 0];
+              pm0 = S.t.stretch[dk & 32767];
+              pm1 = S.t.stretch[(-dk) & 32767];
+            }
             nibble_finish();
           }
 
