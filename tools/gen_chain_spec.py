@@ -73,13 +73,13 @@ def gen(name, spec_id, header):
             out.append("  {")
             if t == T["isse"]:
                 out.append("    " + operand("pj", c[2], i))
-                out.append("    const int v = zhcore::clamp2k((me.w0 * pj + me.w1 * 64) >> 16);")
+                out.append("    const int v = zhcore::clamp2k((__mul24(me.w0, pj) + me.w1 * 64) >> 16);")
                 out.append(f"    const bool mine = lane == {i}u;")
                 out.append("    me.p = mine ? v : me.p; me.pj = mine ? pj : me.pj;")
             elif t == T["mix2"]:
                 out.append("    " + operand("pj", c[2], i))
                 out.append("    " + operand("pk", c[3], i))
-                out.append("    const int v = (me.w0 * pj + (65536 - me.w0) * pk) >> 16;")
+                out.append("    const int v = (__mul24(me.w0, pj) + __mul24(65536 - me.w0, pk)) >> 16;")
                 out.append(f"    const bool mine = lane == {i}u;")
                 out.append("    me.p = mine ? v : me.p; me.pj = mine ? pj : me.pj; me.pk = mine ? pk : me.pk;")
             elif t == T["avg"]:
@@ -107,7 +107,7 @@ def gen(name, spec_id, header):
                 continue
             j0, m = comps[mi][2], comps[mi][3]
             out.append(f"  {{  // MIX {mi}: inputs {j0}..{j0 + m - 1}, weights me.mw[{q}]")
-            out.append(f"    const int term = (lane >= {j0}u && lane < {j0 + m}u) ? (me.mw[{q}] >> 8) * me.p : 0;")
+            out.append(f"    const int term = (lane >= {j0}u && lane < {j0 + m}u) ? __mul24(me.mw[{q}] >> 8, me.p) : 0;")
             out.append("    const int sum = zhdev::wave_sum(term);")
             out.append(f"    me.p = lane == {mi}u ? zhcore::clamp2k(sum >> 8) : me.p;")
             out.append("  }")

@@ -60,6 +60,8 @@ struct alignas(16) ChainLds {
 };
 static_assert(sizeof(ChainLds) <= 163840, "LDS budget");
 
+// Products of a 20-bit weight or error term and a 12-bit stretched prediction use the full-rate 24-bit multiplier
+// (__mul24 -> v_mul_i32_i24); both operands are bounded by clamp512k / clamp2k / squash, so the results are exact.
 __device__ __forceinline__ int clampk(int x, int lo, int hi) { return x < lo ? lo : x > hi ? hi : x; }
 // Typed LDS accesses by LDS byte offset: lets one ds_* instruction serve lanes of different component types
 // (the address is selected per lane) instead of one divergent branch per type.
@@ -467,11 +469,11 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
                 const int pj = (int)rdlane((uint32_t)me.p, (desc >> 16) & 63);
                 const bool mine = lane == one;
                 if (LIKELY(typ == ZH_ISSE)) {
-                  const int v = clamp2k((me.w0 * pj + me.w1 * 64) >> 16);
+                  const int v = clamp2k((__mul24(me.w0, pj) + me.w1 * 64) >> 16);
                   me.p = mine ? v : me.p; me.pj = mine ? pj : me.pj;
                 } else if (typ == ZH_MIX2) {
                   const int pk = (int)rdlane((uint32_t)me.p, (desc >> 24) & 63);
-                  const int v = (me.w0 * pj + (65536 - me.w0) * pk) >> 16;
+                  const int v = (__mul24(me.w0, pj) + __mul24(65536 - me.w0, pk)) >> 16;
                   me.p = mine ? v : me.p; me.pj = mine ? pj : me.pj; me.pk = mine ? pk : me.pk;
                 } else if (typ == ZH_AVG) {
                   const int pk = (int)rdlane((uint32_t)me.p, (desc >> 24) & 63);
@@ -497,9 +499,9 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
                 if (me.level == lv) {
                   me.pj = pj; me.pk = pk;
                   switch (me.type) {
-                    case ZH_ISSE: me.p = clamp2k((me.w0 * pj + me.w1 * 64) >> 16); break;
+                    case ZH_ISSE: me.p = clamp2k((__mul24(me.w0, pj) + me.w1 * 64) >> 16); break;
                     case ZH_AVG: me.p = (pj * (int)me.a2 + pk * (256 - (int)me.a2)) >> 8; break;
-                    case ZH_MIX2: me.p = (me.w0 * pj + (65536 - me.w0) * pk) >> 16; break;
+                    case ZH_MIX2: me.p = (__mul24(me.w0, pj) + __mul24(65536 - me.w0, pk)) >> 16; break;
                     case ZH_SSE: {
                       me.cxt = (me.h + c8) * 32u;
                       int pq = clampk(pj + 992, 0, 1983);
@@ -523,7 +525,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
                 for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {
                   if (q >= (kSpec ? SP::nmix : nmix)) break;
                   if (mq != 7 ? mq != q + 1 : mx_lv[q] != lv) continue;
-                  const int term = (me.memb >> q & 1) ? (me.mw[q] >> 8) * me.p : 0;
+                  const int term = (me.memb >> q & 1) ? __mul24(me.mw[q] >> 8, me.p) : 0;
                   const int sum = wave_sum(term);
                   if (lane == mx_lane[q]) me.p = clamp2k(sum >> 8);
                 }
@@ -541,13 +543,13 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
 
             ZH_STAMP(2);
             // ================= update (Predictor.cs:363-461) =================
-            const int emix = (y * 32767 - sqp) * (int)me.a3 >> 4;   // MIX error term (meaningful in mixer lanes)
+            const int emix = __mul24(y * 32767 - sqp, (int)me.a3) >> 4;   // MIX error term (meaningful in mixer lanes)
 #pragma unroll
             for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {      // MIX: error from the mixer lane, weights in the input lanes
               if (q >= (kSpec ? SP::nmix : nmix)) break;
               const int eq = (int)rdlane((uint32_t)emix, mx_lane[q]);
               if (me.memb >> q & 1) {
-                me.mw[q] = clamp512k(me.mw[q] + ((eq * me.p + (1 << 12)) >> 13));
+                me.mw[q] = clamp512k(me.mw[q] + ((__mul24(eq, me.p) + (1 << 12)) >> 13));
                 reinterpret_cast<uint32_t *>(slot_mem + mx_off[q])[rows[q] + (lane - mx_j0[q])] = (uint32_t)me.mw[q];
               }
             }
@@ -566,7 +568,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
               *(lds_u8_p)(is_ii ? slot_off + hm15 : dummy_off) = (uint8_t)(pns >> (y * 8));   // StateTable.next
               const int e = y * 32767 - sqp;
               const uint32_t n0 = is_icm ? pv + (uint32_t)((int)(y * 32767 - (int)(pv >> 8)) >> 2)
-                                         : (uint32_t)clamp512k(me.w0 + ((e * me.pj + (1 << 12)) >> 13));
+                                         : (uint32_t)clamp512k(me.w0 + ((__mul24(e, me.pj) + (1 << 12)) >> 13));
               const uint32_t n1 = (uint32_t)clamp512k(me.w1 + ((e + 16) >> 5));
               *(lds_u32_p)(is_ii ? ii_a : dummy_off) = n0;
               *(lds_u32_p)(is_isse ? ii_a + 4 : dummy_off) = n1;
@@ -577,7 +579,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
               ++me.cxt;                                  // finished at the byte boundary below
             }
             if (ZH_HAS(ZH_MIX2) && me.type == ZH_MIX2) {
-              const int e = (y * 32767 - sqp) * (int)me.a3 >> 5;
+              const int e = __mul24(y * 32767 - sqp, (int)me.a3) >> 5;
               int w = me.w0 + ((e * (me.pj - me.pk) + (1 << 12)) >> 13);
               w = clampk(w, 0, 65535);
               reinterpret_cast<uint16_t *>(slot_mem + me.cmo)[me.cxt] = (uint16_t)w;
