@@ -330,7 +330,7 @@ def test_python_mirror_of_the_reference_api(ctx):
     w = D.BytesWriter()
     D.decompress(D.BytesReader(s), w, context=ctx)
     assert bytes(w.buf) == a + b + c == oracle.decompress(s)
-    # documented step-wise order, decompress(n) resumption, sha1 string, hcomp()
+    # documented step-wise order, decompress(n) resumption, sha1 string, hcomp(), pcomp()
     d, od = D.Decompresser(ctx), oracle.Decompresser(s)
     d.setInput(D.BytesReader(s))
     names, total = [], bytearray()
@@ -355,6 +355,8 @@ def test_python_mirror_of_the_reference_api(ctx):
                 calls += 1
             want, _ = od.decompress()
             assert bytes(out.buf) == want and calls == len(want) // 1000
+            pw = D.BytesWriter()                            # pcomp(): false / nothing for PASS blocks, else len + program
+            assert d.pcomp(pw) == bool(od.pcomp()) and bytes(pw.buf) == od.pcomp()
             stored = d.readSegmentEnd()
             assert stored == od.read_segment_end() == sha.digest()
             names.append(bytes(fn.buf)); total += out.buf
@@ -398,6 +400,7 @@ int main(int argc, char **argv) {
   d.setInput(&in);
   Out o2; d.setOutput(&o2);
   int segs = 0, with_sha = 0;
+  size_t pcomp_bytes = 0;
   while (d.findBlock()) {
     Out name;
     while (d.findFilename(&name)) {
@@ -406,8 +409,10 @@ int main(int argc, char **argv) {
       char sha[21]; d.readSegmentEnd(sha);
       ++segs; with_sha += sha[0];
     }
+    Out pc;
+    if (d.pcomp(&pc)) pcomp_bytes += pc.s.size();
   }
-  printf("OK %zu %d %d %d\n", out.s.size(), o2.s == out.s, segs, with_sha);
+  printf("OK %zu %d %d %d %zu\n", out.s.size(), o2.s == out.s, segs, with_sha, pcomp_bytes);
   return 0;
 }
 '''
@@ -426,7 +431,7 @@ def test_cpp_mirror_of_the_reference_api(ctx, tmp_path):
                            str(tmp_path / "t.cpp"), "-o", str(exe), "-L", lib, "-lzpaqhip", f"-Wl,-rpath,{lib}",
                            "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([str(exe), str(tmp_path / "in.zpaq"), str(tmp_path / "out.bin")]).decode()
-    assert out.split() == ["OK", str(len(a) + len(b)), "1", "2", "2"], out
+    assert out.split() == ["OK", str(len(a) + len(b)), "1", "2", "2", str(len(models.get("max+e8e9").pcomp) + 2)], out
     assert (tmp_path / "out.bin").read_bytes() == a + b
 
 

@@ -57,7 +57,8 @@ WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_int)
 # Every symbol include/zpaqhip.h declares; tests check the library exports them all.
 SYMBOLS = ("zpaqhip_version", "zpaqhip_strerror", "zpaqhip_device_count", "zpaqhip_ctx_create",
            "zpaqhip_ctx_destroy", "zpaqhip_last_stats", "zpaqhip_scan", "zpaqhip_decompress",
-           "zpaqhip_decompress_segments", "zpaqhip_decompress_cb", "zpaqhip_decode_blocks_device", "zpaqhip_read_device_tables")
+           "zpaqhip_decompress_segments", "zpaqhip_decompress_cb", "zpaqhip_decode_blocks_device", "zpaqhip_read_device_tables",
+           "zpaqhip_block_pcomp")
 
 _lib = None
 
@@ -96,5 +97,6 @@ def load():
                                                C.POINTER(C.c_uint32), sz, vp, C.POINTER(C.c_uint64),
                                                C.POINTER(C.c_uint64), C.POINTER(SegResult), C.POINTER(Opts), vp, errp]
     L.zpaqhip_read_device_tables.argtypes = [vp, vp, vp, vp, vp, vp, errp]
+    L.zpaqhip_block_pcomp.argtypes = [vp, vp, sz, C.c_uint32, vp, sz, C.POINTER(sz), errp]
     _lib = L
     return L

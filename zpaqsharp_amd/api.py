@@ -149,6 +149,17 @@ class Context:
             _raise(err, rc)
         return out[:n.value]
 
+    def block_pcomp(self, stream, block: int) -> bytes:
+        """Decompresser.pcomp() (Decompresser.cs:155-158): b"" if block `block` has no PCOMP, else
+        length-lo, length-hi, program bytes (ZPAQL.write(out, true), ZPAQL.cs:171-177)."""
+        a = _as_u8(stream)
+        err, n = Err(), C.c_size_t(0)
+        out = np.empty(65536 + 2, np.uint8)
+        rc = self._L.zpaqhip_block_pcomp(self._h, a.ctypes.data, a.size, block, out.ctypes.data, out.size, C.byref(n), C.byref(err))
+        if rc:
+            _raise(err, rc)
+        return out[:n.value].tobytes()
+
     def decompress_segments(self, stream, **opt):
         """Whole stream, but per-segment outcomes are returned instead of raised:
         (plaintext ndarray, SegResult array indexed like scan(stream).segments)."""

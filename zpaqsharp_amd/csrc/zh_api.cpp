@@ -49,6 +49,7 @@ struct zpaqhip_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf tables, fused, arena, models, code, bdesc, sdesc, results, queue, in, out;
   zpaqhip_stats stats{};
+  std::vector<uint32_t> raw_pp;           // last decode: per segment pp_state | PCOMP length << 8, as the kernels report it
 };
 
 namespace {
@@ -345,6 +346,7 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     fprintf(stderr, "\n");
   }
   std::vector<ZhSegResult> res(n_segs);
+  c->raw_pp.assign(n_segs, 0);
   HIPCHK(hipMemcpyAsync(res.data(), c->results.p, n_segs * sizeof(ZhSegResult), hipMemcpyDeviceToHost, stream));
   HIPCHK(hipStreamSynchronize(stream));
   float ms = 0;
@@ -357,7 +359,8 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     for (uint32_t s = 0; s < b.n_seg; ++s) {
       const uint32_t si = b.first_seg + s;
       results[si].status = res[si].status;
-      results[si].pp_state = res[si].pp_state;
+      results[si].pp_state = res[si].pp_state & 255u;
+      c->raw_pp[si] = res[si].pp_state;
       results[si].out_off = res[si].out_off;
       results[si].out_len = res[si].out_len;
       results[si].in_used = res[si].in_used;
@@ -534,6 +537,51 @@ int zpaqhip_decompress_segments(zpaqhip_ctx *c, const uint8_t *in, size_t in_len
       if (memcmp(d, so.segs[s].sha1, 20)) results[s].status = ZPAQHIP_E_SHA1;
     }
   }
+  return ZPAQHIP_OK;
+}
+
+// Decompresser.pcomp (Decompresser.cs:155-158 -> ZPAQL.write(out, true), ZPAQL.cs:158-179): the PCOMP program a block's
+// first segment carries, as "length lo, length hi, program bytes"; *out_len = 0 when the block has none.  The program
+// travels inside the coded data, so the block is decoded (counting only, one arena slot) and the program is read back
+// from that slot.
+int zpaqhip_block_pcomp(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint32_t block, uint8_t *out, size_t out_cap,
+                        size_t *out_len, zpaqhip_err *err) {
+  if (!c || (!in && in_len) || !out_len || (!out && out_cap)) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
+  *out_len = 0;
+  ScanOut so;
+  int rc = scan_stream(in, in_len, so, err);
+  if (rc) return rc;
+  if (block >= so.blocks.size()) { set_err(err, ZPAQHIP_E_ARG, (int)block, -1, "block id out of range"); return ZPAQHIP_E_ARG; }
+  const zpaqhip_block &b = so.blocks[block];
+  if (b.n_seg == 0) return ZPAQHIP_OK;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(c->in.reserve(in_len + 16));
+  HIPCHK(hipMemcpy(c->in.p, in, in_len, hipMemcpyHostToDevice));
+  HIPCHK(c->out.reserve(16));
+  zpaqhip_opts o;
+  memset(&o, 0, sizeof o);
+  o.struct_size = sizeof o;
+  o.max_concurrent = 1;                                  // the block runs in arena slot 0
+  std::vector<zpaqhip_seg_result> res(so.segs.size());
+  const uint32_t id = block;
+  const uint64_t off0 = 0, cap0 = 0;                     // count-only: nothing is written
+  rc = zpaqhip_decode_blocks_device(c, c->in.p, in, in_len, so.blocks.data(), so.blocks.size(), so.segs.data(), so.segs.size(),
+                                    &id, 1, c->out.p, &off0, &cap0, res.data(), &o, c->stream, err);
+  const uint32_t raw = c->raw_pp.size() > b.first_seg ? c->raw_pp[b.first_seg] : 0;
+  const uint32_t state = raw & 255u, hsize = raw >> 8;
+  if (state < 5) {                                       // PASS, or the stream broke before the program was complete
+    if (rc && rc != ZPAQHIP_E_OUTPUT_FULL && res[b.first_seg].status != ZPAQHIP_OK && res[b.first_seg].status != ZPAQHIP_E_OUTPUT_FULL) return rc;
+    return ZPAQHIP_OK;
+  }
+  *out_len = (size_t)hsize + 2;
+  if (*out_len > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, (int)block, (int)b.first_seg); return ZPAQHIP_E_OUTPUT_FULL; }
+  std::vector<uint8_t> code;
+  ZhModel m;
+  rc = build_model(in + b.hdr_off, b.hdr_len, m, code, err);
+  if (rc) return rc;
+  out[0] = (uint8_t)(hsize & 255);
+  out[1] = (uint8_t)(hsize >> 8);
+  HIPCHK(hipMemcpy(out + 2, (const uint8_t *)c->arena.p + m.pz_off + ZH_CODE_PAD, hsize, hipMemcpyDeviceToHost));
   return ZPAQHIP_OK;
 }
 

@@ -660,7 +660,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
       if (status && status != ZH_E_OUTPUT_FULL) failed = 1;
       if (lane == 0) {
         ZhSegResult res;
-        res.status = status; res.pp_state = (uint32_t)pp_state;
+        res.status = status; res.pp_state = (uint32_t)pp_state | (uint32_t)pp_hsize << 8;   // PCOMP length rides in bits 8-23
         res.out_off = b_out_off + produced0; res.out_len = produced - produced0;
         res.in_used = in_pos(in) - seg_off;
         L.results[si] = res;

@@ -283,7 +283,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_generic(ZhLaunch L) {
         }
         if (!status && out.len > out.cap) status = ZH_E_OUTPUT_FULL;
         if (status && status != ZH_E_OUTPUT_FULL) failed = 1;
-        res.status = status; res.pp_state = (uint32_t)pp.state; res.out_len = out.len - start;
+        res.status = status; res.pp_state = (uint32_t)pp.state | (uint32_t)pp.hsize << 8; res.out_len = out.len - start;
         res.in_used = (uint64_t)(in.p - (L.in + sd.in_off));
         L.results[si] = res;
       }

@@ -197,8 +197,11 @@ class Decompresser:
             return False
         return True
 
-    def pcomp(self, out: Writer) -> bool:     # Decompresser.cs:155-158 — not available from the GPU path yet
-        raise NotImplementedError("pcomp() read-back is a 'next' row (DESIGN.md §8)")
+    def pcomp(self, out: Writer) -> bool:     # Decompresser.cs:155-158: false when the block has no PCOMP
+        prog = self._ctx.block_pcomp(self._stream, self._b)
+        if prog:
+            out.write(prog)
+        return bool(prog)
 
     # ---- Decompresser.cs:163-194
     def readSegmentEnd(self) -> Optional[bytes]:

@@ -71,6 +71,15 @@ class Decompresser {
     const zpaqhip_block &b = blocks_[b_];
     out->write((const char *)stream_.data() + b.hdr_off, (int)b.hdr_len);
   }
+  bool pcomp(Writer *out) {                                                     // Decompresser.cs:155-158
+    std::vector<uint8_t> buf(65536 + 2);
+    size_t n = 0;
+    zpaqhip_err e;
+    int rc = zpaqhip_block_pcomp(ctx_, stream_.data(), stream_.size(), (uint32_t)b_, buf.data(), buf.size(), &n, &e);
+    if (rc) throw Error(rc, (int)b_, -1);
+    if (n) out->write((const char *)buf.data(), (int)n);
+    return n != 0;
+  }
   bool findFilename(Writer *filename = nullptr) {                               // Decompresser.cs:67-93
     const zpaqhip_block &b = blocks_[b_];
     if (s_ + 1 >= (long)(b.first_seg + b.n_seg)) return false;
