@@ -19,9 +19,9 @@
 #include "zh_host.h"
 
 extern "C" hipError_t zh_launch_generic(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
-extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream);
+extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof);
-extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, const uint16_t *fused, uint32_t grid, hipStream_t stream);
+extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 
 
 using namespace zh;
@@ -47,7 +47,7 @@ struct zpaqhip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  DevBuf tables, fused, arena, models, code, bdesc, sdesc, results, queue, in, out;
+  DevBuf tables, arena, models, code, bdesc, sdesc, results, queue, in, out;
   zpaqhip_stats stats{};
   std::vector<uint32_t> raw_pp;           // last decode: per segment pp_state | PCOMP length << 8, as the kernels report it
 };
@@ -113,19 +113,6 @@ int zpaqhip_ctx_create(int device, zpaqhip_ctx **out, zpaqhip_err *err) {
     zpaqhip_ctx_destroy(c);
     return ZPAQHIP_E_HIP;
   }
-  {  // fused squash(stretch(x))*2+1 table for single-CM models (zh_cm.hip)
-    const ZhTables &t = host_tables();
-    std::vector<uint16_t> fused(32768);
-    for (int x = 0; x < 32768; ++x) fused[x] = (uint16_t)(t.squash[t.stretch[x] + 2048] * 2 + 1);
-    if ((e = c->fused.reserve(65536)) != hipSuccess ||
-        (e = hipMemcpy(c->fused.p, fused.data(), 65536, hipMemcpyHostToDevice)) != hipSuccess) {
-      char m[112];
-      snprintf(m, sizeof m, "HIP: %s (context setup)", hipGetErrorString(e));
-      set_err(err, ZPAQHIP_E_HIP, -1, -1, m);
-      zpaqhip_ctx_destroy(c);
-      return ZPAQHIP_E_HIP;
-    }
-  }
   *out = c;
   return ZPAQHIP_OK;
 }
@@ -133,7 +120,7 @@ int zpaqhip_ctx_create(int device, zpaqhip_ctx **out, zpaqhip_err *err) {
 void zpaqhip_ctx_destroy(zpaqhip_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (DevBuf *b : {&c->tables, &c->fused, &c->arena, &c->models, &c->code, &c->bdesc, &c->sdesc, &c->results, &c->queue, &c->in, &c->out})
+  for (DevBuf *b : {&c->tables, &c->arena, &c->models, &c->code, &c->bdesc, &c->sdesc, &c->results, &c->queue, &c->in, &c->out})
     b->release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -328,8 +315,8 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     L.budget = opts.zpaql_budget;
     const bool prof = getenv("ZPAQHIP_PROF") != nullptr;   // diagnostic build with in-kernel stamps
     if (prof) { L.debug = (uint64_t *)c->queue.p + 16; HIPCHK(hipMemsetAsync(L.debug, 0, 64, stream)); }
-    if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, (const uint16_t *)c->fused.p, slots_of[g], stream));
-    else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, (const uint16_t *)c->fused.p, slots_of[g], stream));
+    if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, slots_of[g], stream));
+    else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, slots_of[g], stream));
     else if (g >= ZH_FAM_CHAIN) HIPCHK(zh_launch_chain(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));
     else HIPCHK(zh_launch_generic(&L, slots_of[g], stream));
     ++launches;

@@ -34,6 +34,10 @@
 using namespace zhcore;
 using namespace zhdev;
 
+// LDS byte offsets are turned into address_space(3) pointers (32-bit on the device); the host pass of hipcc, which
+// never runs this code, sees 64-bit pointers there and would warn.
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+
 namespace {
 
 constexpr int kSmallWords = 16384;        // LDS pool for ICM (256 words) / ISSE (512 words) tables
@@ -72,7 +76,7 @@ __device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(u
 
 // Per-lane view of one component (Component.cs:18-57 + its header arguments).
 struct ZhSpec_generic {                    // run-time everything (any header the host accepts for this family)
-  static constexpr uint32_t id = 0u, n = 0u, types = 0x3ffu, nmix = 0u, depth = 0u;
+  static constexpr uint32_t id = 0u, types = 0x3ffu, nmix = 0u;
 };
 
 struct Lane {
@@ -90,31 +94,6 @@ struct Lane {
   uint32_t memb;                          // bit q set: this lane feeds mixer q
   bool rowvalid;                          // slot holds a row/line that must be written back
 };
-
-// Predictor.find (Predictor.cs:550-567) for one lane: probe the three candidate rows,
-// pick / recycle one, and leave it in the lane's LDS slot.  Returns the row offset.
-__device__ __forceinline__ uint32_t find_row_lds(uint8_t *ht, uint32_t ht_mask, int sizebits, uint32_t cxt,
-                                                 uint8_t *slot) {
-  const uint32_t chk = (cxt >> sizebits) & 255;
-  const uint32_t h0 = (cxt * 16u) & (ht_mask - 15u), h1 = h0 ^ 16, h2 = h0 ^ 32;
-  const uint4 r0 = *reinterpret_cast<const uint4 *>(ht + h0);
-  const uint4 r1 = *reinterpret_cast<const uint4 *>(ht + h1);
-  const uint4 r2 = *reinterpret_cast<const uint4 *>(ht + h2);
-  uint32_t sel;
-  uint4 row;
-  if ((r0.x & 255) == chk) { sel = h0; row = r0; }
-  else if ((r1.x & 255) == chk) { sel = h1; row = r1; }
-  else if ((r2.x & 255) == chk) { sel = h2; row = r2; }
-  else {
-    const uint32_t p0 = (r0.x >> 8) & 255, p1 = (r1.x >> 8) & 255, p2 = (r2.x >> 8) & 255;
-    if (p0 <= p1 && p0 <= p2) sel = h0;
-    else if (p1 < p2) sel = h1;
-    else sel = h2;
-    row = make_uint4(chk, 0, 0, 0);
-  }
-  *reinterpret_cast<uint4 *>(slot) = row;
-  return sel;
-}
 
 template <bool PROF, class SP>
 __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S) {

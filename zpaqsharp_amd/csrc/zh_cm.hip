@@ -39,6 +39,10 @@
 using namespace zhcore;
 using namespace zhdev;
 
+// LDS byte offsets are turned into address_space(3) pointers (32-bit on the device); the host pass of hipcc, which
+// never runs this code, sees 64-bit pointers there and would warn.
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+
 namespace {
 
 constexpr uint32_t kWin = 64;             // LDS-resident windows: one tag per lane of wave A
@@ -687,12 +691,12 @@ extern "C" __global__ __launch_bounds__(128) void zh_decode_cm_prof(ZhLaunch L) 
   decode_cm_body<true>(L, S);
 }
 
-extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, const uint16_t *, uint32_t grid, hipStream_t stream) {
+extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream) {
   hipLaunchKernelGGL(zh_decode_cm_prof, dim3(grid), dim3(128), 0, stream, *L);
   return hipGetLastError();
 }
 
-extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, const uint16_t *, uint32_t grid, hipStream_t stream) {
+extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, uint32_t grid, hipStream_t stream) {
   hipLaunchKernelGGL(zh_decode_cm, dim3(grid), dim3(128), 0, stream, *L);
   return hipGetLastError();
 }
