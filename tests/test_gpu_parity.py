@@ -138,6 +138,23 @@ def test_two_wave_cm_kernel_stress(ctx):
     assert ctx.decompress(s, verify_sha1=True).tobytes() == b"".join(parts)
 
 
+@pytest.mark.parametrize("model", ["l1+lz77", "mid+lz77", "min+lz77"])
+def test_lz77_postprocessor_with_memory_in_hbm(ctx, model):
+    """A PCOMP program whose memory does not fit on chip: the LZ77 post-processor of models.LZ77_PCOMP keeps a
+    64 KiB history in M (arena slot in HBM) and runs on the ZPAQL interpreter of every kernel."""
+    rng = np.random.default_rng(5)
+    parts = [util.text(120000, seed=21), b"ab" * 40000 + util.x86ish(30000, 7), b"",
+             bytes(rng.integers(0, 256, 5000, dtype=np.uint8)) * 3]
+    m = models.get(model)
+    s = b"".join(synth.compress_block(m, d) for d in parts)
+    assert len(s) < sum(map(len, parts)) // 2                   # the matches really are used
+    want = b"".join(parts)
+    assert oracle.decompress(s[:len(synth.compress_block(m, parts[0]))]) == parts[0]
+    for kernel in (0, 1):
+        assert ctx.decompress(s, verify_sha1=True, kernel=kernel).tobytes() == want
+    assert ctx.block_pcomp(s, 0)[2:] == m.pcomp
+
+
 def test_multi_segment_blocks(ctx):
     for model in ("l1", "mid", "max+e8e9"):
         m = models.get(model)

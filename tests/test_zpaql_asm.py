@@ -38,3 +38,18 @@ def test_long_jumps():
     body = " ".join(["a++"] * 200)
     prog = zpaql.assemble(f"comp 0 0 0 0 0 hcomp halt pcomp x ; a> 255 ifnotl {body} out endif halt end").pcomp
     assert oracle.run_pcomp(prog, bytes([1])) == bytes([201])
+
+
+def test_lz77_model_round_trips_on_the_oracle():
+    import numpy as np
+    import oracle
+    from tests import util
+    from zpaqsharp_amd import models, synth
+    m = models.get("l1+lz77")
+    assert zpaql.parse_header(m.header)[3] == 16 and m.pcomp_cmd.startswith("lz77")
+    rng = np.random.default_rng(2)
+    for d in (util.text(30000, 4), b"a" * 4000, b"", b"xy", bytes(rng.integers(0, 256, 2000, dtype=np.uint8)), util.x86ish(9000, 6)):
+        enc = synth.lz77_encode(d)
+        s = synth.compress_block(m, d)
+        assert oracle.decompress(s) == d
+        assert len(enc) <= len(d) + len(d) // 8 + 2          # never much worse than stored

@@ -143,6 +143,46 @@ end
 """
 
 
+# A byte-oriented LZ77 post-processor with a 64 KiB history in M (the reference builds its LZ77 programs per method
+# string, LibZPAQ.cs:427-639; this one is this repo's own, written for the tests of PCOMP programs whose memory lives
+# in HBM).  Coded form (synth.lz77_encode): token t < 128: t + 1 literal bytes follow;  t >= 128: a match of
+# (t & 127) + 3 bytes at distance lo + 256 * hi (two bytes follow, distance >= 1; source and destination may overlap).
+# R0 = mode (0 token, 1 literals, 2 distance low byte, 3 distance high byte), R1 = bytes left, R2 = distance low byte,
+# C = write position in the history ring M.
+LZ77_PCOMP = """
+pcomp lz77inv ;
+  a> 255 if halt endif           (end of segment: nothing is buffered)
+  b=a                            (the coded byte)
+  a=r 0
+  a== 0 if                       (token)
+    a=b a> 127 if
+      a&= 127 a+= 3 r=a 1  a= 2 r=a 0
+    else
+      a++ r=a 1  a= 1 r=a 0
+    endif
+    halt
+  endif
+  a== 1 if                       (literal)
+    a=b *c=a c++ out
+    a=r 1 a-- r=a 1
+    a== 0 if r=a 0 endif
+    halt
+  endif
+  a== 2 if
+    a=b r=a 2  a= 3 r=a 0 halt
+  endif
+  a=b a<<= 8 d=a a=r 2 a+=d d=a  (distance)
+  a=c a-=d b=a                   (source position)
+  do
+    a=*b *c=a out b++ c++
+    a=r 1 a-- r=a 1 a> 0
+  while
+  a=0 r=a 0
+  halt
+end
+"""
+
+
 def _with_pcomp(cfg: str, pcomp: str, pm: int) -> str:
     """Attach a PCOMP section to a config and set its M size (pm)."""
     lines = cfg.strip().splitlines()
@@ -156,13 +196,15 @@ def _with_pcomp(cfg: str, pcomp: str, pm: int) -> str:
 
 @lru_cache(maxsize=None)
 def get(name: str) -> Model:
-    """Models by name: l1, min, mid, max, and `<name>+e8e9` for any of them."""
+    """Models by name: l1, min, mid, max, and `<name>+e8e9` / `<name>+lz77` for any of them."""
     base, _, post = name.partition("+")
     cfg = {"l1": L1_CFG, "min": MIN_CFG, "mid": MID_CFG, "max": MAX_CFG}[base]
     if post == "":
         return assemble(cfg)
     if post == "e8e9":
         return assemble(_with_pcomp(cfg, E8E9_PCOMP, pm=3))
+    if post == "lz77":
+        return assemble(_with_pcomp(cfg, LZ77_PCOMP, pm=16))
     raise KeyError(name)
 
 

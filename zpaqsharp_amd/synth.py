@@ -68,6 +68,45 @@ def e8e9(data) -> np.ndarray:
     return a
 
 
+def lz77_encode(data) -> np.ndarray:
+    """Greedy LZ77 coder for models.LZ77_PCOMP: literal runs (token t < 128: t + 1 bytes) and matches of 3..130
+    bytes at distance 1..65535 (token 128 + len - 3, distance low byte, high byte)."""
+    d = bytes(_u8(data).tobytes())
+    n, out, lits, last, i = len(d), bytearray(), bytearray(), {}, 0
+
+    def flush():
+        for k in range(0, len(lits), 128):
+            run = lits[k:k + 128]
+            out.append(len(run) - 1)
+            out.extend(run)
+        lits.clear()
+
+    while i < n:
+        best = 0
+        if i + 3 <= n:
+            key = d[i:i + 3]
+            j = last.get(key, -1)
+            if j >= 0 and i - j <= 65535:
+                m = 3
+                while m < 130 and i + m < n and d[j + m] == d[i + m]:
+                    m += 1
+                best, dist = m, i - j
+            last[key] = i
+        if best >= 3:
+            flush()
+            out.append(128 + best - 3)
+            out.append(dist & 255)
+            out.append(dist >> 8)
+            for k in range(i + 1, min(i + best, n - 2)):
+                last[d[k:k + 3]] = k
+            i += best
+        else:
+            lits.append(d[i])
+            i += 1
+    flush()
+    return np.frombuffer(bytes(out), np.uint8)
+
+
 def compress_block(model, data, filename: bytes = b"", comment: Optional[bytes] = None, sha1: bool = True,
                    tag: bool = True) -> bytes:
     """One block / one segment in LibZPAQ.compressBlock framing (LibZPAQ.cs:296-323)."""
@@ -76,6 +115,8 @@ def compress_block(model, data, filename: bytes = b"", comment: Optional[bytes] 
     src = d
     if m.pcomp_cmd.startswith("e8e9"):
         src = e8e9(d)
+    elif m.pcomp_cmd.startswith("lz77"):
+        src = lz77_encode(d)
     hdr, pc = _u8(m.header), _u8(m.pcomp) if m.pcomp else None
     cap = d.size + d.size // 8 + len(m.header) + 2 * len(m.pcomp) + 4096
     need = C.c_size_t(0)
