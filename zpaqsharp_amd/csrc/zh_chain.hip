@@ -278,6 +278,8 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
     const bool h_lds = hz.h == S.hreg && hz.m == S.mreg;
     const uint32_t hnative = h_lds ? (uni(M->kind) >> 8) & 255 : 0;   // ahead-of-time translated HCOMP, if known
     uint32_t ha = 0, hb = 0, hc = 0, hd = 0, hf = 0;                  // HCOMP registers A B C D F (wave-uniform)
+    const lds_u8_p lds_m = (lds_u8_p)lds_off(S.mreg);                 // address-space-qualified views for the native programs:
+    const lds_u32_p lds_h = (lds_u32_p)lds_off(S.hreg);               // ds_* instead of flat_* accesses
 
     int pp_state = 0, pp_hsize = 0;                    // PostProcessor (PostProcessor.cs:12-16)
     uint32_t pp_len = 0;
@@ -597,14 +599,14 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             // h[] for the next byte: z.run(c), then H(i) (Predictor.cs:465-469)
             int rc;
             switch (hnative) {                             // native forms of the known programs (tools/gen_zpaql_native.py)
-              case ZH_NATIVE_HCOMP_MIN: rc = zh_native_hcomp_min(ha, hb, hc, hd, hf, (uint32_t)c, S.mreg, hz.mmask, S.hreg, hmask, S.r, (Sink *)nullptr, L.budget); break;
-              case ZH_NATIVE_HCOMP_MID: rc = zh_native_hcomp_mid(ha, hb, hc, hd, hf, (uint32_t)c, S.mreg, hz.mmask, S.hreg, hmask, S.r, (Sink *)nullptr, L.budget); break;
-              case ZH_NATIVE_HCOMP_MAX: rc = zh_native_hcomp_max(ha, hb, hc, hd, hf, (uint32_t)c, S.mreg, hz.mmask, S.hreg, hmask, S.r, (Sink *)nullptr, L.budget); break;
+              case ZH_NATIVE_HCOMP_MIN: rc = zh_native_hcomp_min(ha, hb, hc, hd, hf, (uint32_t)c, lds_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
+              case ZH_NATIVE_HCOMP_MID: rc = zh_native_hcomp_mid(ha, hb, hc, hd, hf, (uint32_t)c, lds_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
+              case ZH_NATIVE_HCOMP_MAX: rc = zh_native_hcomp_max(ha, hb, hc, hd, hf, (uint32_t)c, lds_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
               default: rc = vm_run(hz, (uint32_t)c, nullptr, L.budget); break;
             }
             rc = (int)uni((uint32_t)rc);
             if (rc) { status = rc; break; }
-            me.h = Hptr[lane & hmask];
+            me.h = h_lds ? lds_h[lane & hmask] : Hptr[lane & hmask];   // typed LDS read when H lives there (not a flat access)
             hmap4 = 1; c8 = 1;
             nibble_issue();                                // rows of the next byte's first nibble: in flight during MATCH
             ZH_STAMP(6);
@@ -649,7 +651,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
         } else if (pp_state == 5) {
           int rc;
           if (pnative == ZH_NATIVE_PCOMP_E8E9)
-            rc = zh_native_pcomp_e8e9(pa, pb, pc_, pd, pf, (uint32_t)c, S.pmreg, pz.mmask, S.phreg, pz.hmask, S.pr, &sink, L.budget);
+            rc = zh_native_pcomp_e8e9(pa, pb, pc_, pd, pf, (uint32_t)c, (lds_u8_p)lds_off(S.pmreg), pz.mmask, (lds_u32_p)lds_off(S.phreg), pz.hmask, S.pr, &sink, L.budget);
           else rc = vm_run(pz, (uint32_t)c, &sink, L.budget);
           rc = (int)uni((uint32_t)rc);
           if (rc) { status = rc; break; }
