@@ -217,7 +217,7 @@ def main():
         "config": {
             "workload": f"BASELINE configs[1]: {nb} x {bs >> 20} MiB independent blocks per GPU, "
                         f"model {model_name} ({model.n} component(s)), plaintext generator {kind}",
-            "model": model_name, "blocks_per_gpu": nb, "block_bytes": bs, "plaintext": kind,
+            "zpaq_model": model_name, "blocks_per_gpu": nb, "block_bytes": bs, "plaintext": kind,
             "coded_over_plain": round(rho, 4), "parallelism": f"blocks x{world} (no data-path collective)",
             "kernel_kind": int(st.kernel_kind), "blocks_in_flight": int(st.concurrent),
         },

@@ -98,6 +98,7 @@ struct Lane {
 template <bool PROF, class SP>
 __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S) {
   constexpr bool kSpec = SP::id != 0;
+  constexpr bool kDefer = SP::id == 1 || SP::id == 2;   // deferred mixer-weight store (measured: helps min / mid, not max)
 #define ZH_HAS(t) ((SP::types >> (t)) & 1u)
   uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tprev = 0;
@@ -311,50 +312,57 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
 
     // Start of a nibble (c8 == 1 or 16 <= c8 < 32): write the old row/line back, fetch the new one.
     // Split in two so that other global traffic can be put in flight between issue and use.
-    uint4 nr0 = make_uint4(0, 0, 0, 0), nr1 = nr0, nr2 = nr0, nr3 = nr0;
+    // The three candidate rows of an ICM / ISSE (Predictor.find, Predictor.cs:550-567) are requested by EVERY lane
+    // (other lanes read the first bytes of the arena slot and ignore them): no divergent region, so the probes leave
+    // back to back and are waited for once.  A CM's 64-byte line takes the same path through four registers.
+    uint4 nr0 = make_uint4(0, 0, 0, 0), nr1 = nr0, nr2 = nr0, nr3 = nr0;   // rows in flight across the byte boundary
     uint32_t nh0 = 0;
-    auto nibble_issue = [&]() __attribute__((always_inline)) {
-      if (me.type == ZH_ICM || me.type == ZH_ISSE) {
-        if (me.rowvalid) *reinterpret_cast<uint4 *>(slot_mem + me.hto + me.c) = *reinterpret_cast<const uint4 *>(myslot);
-        const uint32_t cxt = me.h + 16u * c8;              // Predictor.find, Predictor.cs:550-567
-        nh0 = (cxt * 16u) & (me.ht_mask - 15u);
-        nr0 = *reinterpret_cast<const uint4 *>(slot_mem + me.hto + nh0);
-        nr1 = *reinterpret_cast<const uint4 *>(slot_mem + me.hto + (nh0 ^ 16));
-        nr2 = *reinterpret_cast<const uint4 *>(slot_mem + me.hto + (nh0 ^ 32));
-      } else if (me.type == ZH_CM) {
+    auto rows_issue = [&](uint4 &r0, uint4 &r1, uint4 &r2, uint4 &r3, uint32_t &h0) __attribute__((always_inline)) {
+      if (is_ii && me.rowvalid) *reinterpret_cast<uint4 *>(slot_mem + me.hto + me.c) = *reinterpret_cast<const uint4 *>(myslot);
+      const uint32_t cxt = me.h + 16u * c8;
+      h0 = is_ii ? (cxt * 16u) & (me.ht_mask - 15u) : 0u;
+      const uint8_t *tb = slot_mem + (is_ii ? me.hto : 0u);
+      r0 = *reinterpret_cast<const uint4 *>(tb + h0);
+      r1 = *reinterpret_cast<const uint4 *>(tb + (h0 ^ 16));
+      r2 = *reinterpret_cast<const uint4 *>(tb + (h0 ^ 32));
+      if (ZH_HAS(ZH_CM) && me.type == ZH_CM) {
         uint4 *g = reinterpret_cast<uint4 *>(slot_mem + me.cmo) + (size_t)me.c * 4;
         const uint4 *l = reinterpret_cast<const uint4 *>(myslot);
         if (me.rowvalid) { g[0] = l[0]; g[1] = l[1]; g[2] = l[2]; g[3] = l[3]; }
         me.c = ((me.h ^ hmap4) & me.cm_mask) >> 4;     // 16-entry line of this nibble
         g = reinterpret_cast<uint4 *>(slot_mem + me.cmo) + (size_t)me.c * 4;
-        nr0 = g[0]; nr1 = g[1]; nr2 = g[2]; nr3 = g[3];
+        r0 = g[0]; r1 = g[1]; r2 = g[2]; r3 = g[3];
       }
     };
-    auto nibble_finish = [&]() __attribute__((always_inline)) {
-      if (me.type == ZH_ICM || me.type == ZH_ISSE) {
-        const uint32_t chk = ((me.h + 16u * c8) >> (me.a0 + 2)) & 255;
-        uint32_t sel;
-        uint4 row;
-        if ((nr0.x & 255) == chk) { sel = nh0; row = nr0; }
-        else if ((nr1.x & 255) == chk) { sel = nh0 ^ 16; row = nr1; }
-        else if ((nr2.x & 255) == chk) { sel = nh0 ^ 32; row = nr2; }
-        else {
-          const uint32_t p0 = (nr0.x >> 8) & 255, p1 = (nr1.x >> 8) & 255, p2 = (nr2.x >> 8) & 255;
-          if (p0 <= p1 && p0 <= p2) sel = nh0;
-          else if (p1 < p2) sel = nh0 ^ 16;
-          else sel = nh0 ^ 32;
-          row = make_uint4(chk, 0, 0, 0);
-        }
+    auto rows_finish = [&](const uint4 &r0, const uint4 &r1, const uint4 &r2, const uint4 &r3, uint32_t h0) __attribute__((always_inline)) {
+      const uint32_t chk = ((me.h + 16u * c8) >> (me.a0 + 2)) & 255;
+      const bool m0 = (r0.x & 255) == chk, m1 = (r1.x & 255) == chk, m2 = (r2.x & 255) == chk;
+      const uint32_t p0 = (r0.x >> 8) & 255, p1 = (r1.x >> 8) & 255, p2 = (r2.x >> 8) & 255;
+      const uint32_t victim = (p0 <= p1 && p0 <= p2) ? h0 : p1 < p2 ? h0 ^ 16 : h0 ^ 32;
+      const uint32_t sel = m0 ? h0 : m1 ? h0 ^ 16 : m2 ? h0 ^ 32 : victim;
+      const uint4 fresh = make_uint4(chk, 0, 0, 0);
+      const uint4 row = m0 ? r0 : m1 ? r1 : m2 ? r2 : fresh;
+      if (is_ii) {
         *reinterpret_cast<uint4 *>(myslot) = row;
         me.c = sel;
         me.rowvalid = true;
-      } else if (me.type == ZH_CM) {
+      }
+      if (ZH_HAS(ZH_CM) && me.type == ZH_CM) {
         uint4 *l = reinterpret_cast<uint4 *>(myslot);
-        l[0] = nr0; l[1] = nr1; l[2] = nr2; l[3] = nr3;
+        l[0] = r0; l[1] = r1; l[2] = r2; l[3] = r3;
         me.rowvalid = true;
       }
     };
-    auto nibble_refresh = [&]() __attribute__((always_inline)) { nibble_issue(); nibble_finish(); };
+    auto nibble_issue = [&]() __attribute__((always_inline)) { rows_issue(nr0, nr1, nr2, nr3, nh0); };
+    auto nibble_finish = [&]() __attribute__((always_inline)) { rows_finish(nr0, nr1, nr2, nr3, nh0); };
+    // issue and use back to back (block start, middle of a byte): the rows live in temporaries, not in the
+    // loop-carried registers of the split form
+    auto nibble_refresh = [&]() __attribute__((always_inline)) {
+      uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, a2 = a0, a3 = a0;
+      uint32_t ah = 0;
+      rows_issue(a0, a1, a2, a3, ah);
+      rows_finish(a0, a1, a2, a3, ah);
+    };
 
     int failed = 0;
     for (uint32_t s = 0; s < n_seg; ++s) {
@@ -391,6 +399,8 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
           if (d.curr != 0) { status = ZH_E_EOS; break; }
           c = -1;
         } else {
+          uint32_t prow[kMaxMix] = {~0u, ~0u, ~0u, ~0u};          // row whose weight (pmw) of the previous bit is not stored yet
+          int pmw[kMaxMix] = {0, 0, 0, 0};
           for (int bit = 0; bit < 8; ++bit) {
             if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
             const uint32_t hm15 = hmap4 & 15;
@@ -401,7 +411,19 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
               if (q >= (kSpec ? SP::nmix : nmix)) break;
               const uint32_t rowv = ((me.h + (c8 & me.a4)) & (me.c - 1)) * mx_m[q];    // valid in the mixer lane
               rows[q] = rdlane(rowv, mx_lane[q]);
-              if (me.memb >> q & 1) me.mw[q] = (int)reinterpret_cast<const uint32_t *>(slot_mem + mx_off[q])[rows[q] + (lane - mx_j0[q])];
+              uint32_t *mrow = reinterpret_cast<uint32_t *>(slot_mem + mx_off[q]) + (lane - mx_j0[q]);
+              if constexpr (kDefer) {
+                // The weight trained at the previous bit is stored only now, AFTER this bit's load has been issued: the
+                // store's round trip then overlaps a whole bit instead of being waited for at the top of the loop.
+                // (Same row twice in a row — a mixer that does not select by c8 — keeps program order.)
+                const bool same = prow[q] == rows[q];          // prow == ~0u: nothing pending
+                if (same && (me.memb >> q & 1)) mrow[prow[q]] = (uint32_t)pmw[q];
+                if (me.memb >> q & 1) me.mw[q] = (int)mrow[rows[q]];
+                if (!same && prow[q] != ~0u && (me.memb >> q & 1)) mrow[prow[q]] = (uint32_t)pmw[q];
+                prow[q] = ~0u;
+              } else {
+                if (me.memb >> q & 1) me.mw[q] = (int)mrow[rows[q]];
+              }
             }
             // Everything update() will need from LDS is fetched here, before the bit is decoded: the entry
             // itself (pv), its adaptation rate (pdt) and BOTH successor states (pns); update() is then
@@ -529,10 +551,9 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             for (uint32_t q = 0; q < (uint32_t)kMaxMix; ++q) {      // MIX: error from the mixer lane, weights in the input lanes
               if (q >= (kSpec ? SP::nmix : nmix)) break;
               const int eq = (int)rdlane((uint32_t)emix, mx_lane[q]);
-              if (me.memb >> q & 1) {
-                me.mw[q] = clamp512k(me.mw[q] + ((__mul24(eq, me.p) + (1 << 12)) >> 13));
-                reinterpret_cast<uint32_t *>(slot_mem + mx_off[q])[rows[q] + (lane - mx_j0[q])] = (uint32_t)me.mw[q];
-              }
+              if (me.memb >> q & 1) me.mw[q] = clamp512k(me.mw[q] + ((__mul24(eq, me.p) + (1 << 12)) >> 13));
+              if (kDefer && bit < 7) { pmw[q] = me.mw[q]; prow[q] = rows[q]; }    // stored after the next bit's load
+              else if (me.memb >> q & 1) reinterpret_cast<uint32_t *>(slot_mem + mx_off[q])[rows[q] + (lane - mx_j0[q])] = (uint32_t)me.mw[q];
             }
             if (ZH_HAS(ZH_CM) && me.type == ZH_CM) {
               const uint32_t cnt = pv & 0x3ff;
