@@ -155,6 +155,33 @@ def test_lz77_postprocessor_with_memory_in_hbm(ctx, model):
     assert ctx.block_pcomp(s, 0)[2:] == m.pcomp
 
 
+def test_many_small_segments_in_one_block(ctx):
+    """Archives pack many small files into one block: every segment end leaves and re-enters the two-wave section of
+    the single-CM kernel (and restarts the coder), the model carries over."""
+    rng = np.random.default_rng(9)
+    for model in ("l1", "min"):
+        m = models.get(model)
+        text = util.text(200000, seed=31)
+        parts, pos = [], 0
+        for i in range(120):
+            n = int(rng.integers(0, 2500)) if i % 7 else 0
+            parts.append(text[pos:pos + n]); pos += n
+        c = oracle.Compressor(400000)
+        c.write_tag(); c.start_block(m.header)
+        for i, part in enumerate(parts):
+            c.start_segment(b"f%d" % i, str(len(part)).encode())
+            if i == 0:
+                c.post_process(m.pcomp)
+            c.compress(part)
+            c.end_segment(oracle.sha1(part) if i % 3 else None)
+        c.end_block()
+        s = c.getvalue()
+        out, res = ctx.decompress_segments(s, verify_sha1=True)
+        assert out.tobytes() == b"".join(parts)
+        assert [int(r.out_len) for r in res[:len(parts)]] == [len(p) for p in parts]
+        assert all(r.status == 0 for r in res[:len(parts)])
+
+
 def test_multi_segment_blocks(ctx):
     for model in ("l1", "mid", "max+e8e9"):
         m = models.get(model)

@@ -64,7 +64,7 @@ struct alignas(16) CmLds {
   uint16_t p16A[kWin][16];                // same for winA
   uint32_t ring[kRing];                   // A -> B messages: tag(7) | type(2) | byte(8) | 0(9) | slot(6)
   uint32_t aux[kRing][2];                 // MISS: new window, victim window
-  uint32_t tags[64];                      // window directory handed to B on ENTER
+  uint32_t tags[64];                      // ENTER: slot s was trained by wave A alone since B last saw it (its p16 is stale)
   uint32_t t0, b_seq;                     // message count at section start / messages completed by B
   uint32_t cmd_seq, cmd_code, cmd_ack;    // A -> B commands outside a section
   uint32_t limit, ob_word, ob_room;
@@ -176,8 +176,8 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
     OutBuf ob;
     ob.base = L.out + uni64(S.ob_base); ob.cap = uni64(S.ob_cap); ob.len = uni64(S.ob_len);
     ob.stored = uni64(S.ob_stored); ob.word = uni(S.ob_word); ob.room = uni(S.ob_room); ob.park = 0;
-    for (uint32_t sl = 0; sl < kWin; ++sl) {
-      if (uni(S.tags[sl]) == kNoWin) continue;
+    for (uint32_t sl = 0; sl < kWin; ++sl) {               // usually one slot (the byte that names the post-processor)
+      if (uni(S.tags[sl]) == 0) continue;
       p16_rebuild(S, sl, lane);
     }
     uint32_t u = uni(S.t0), sp = 0;                        // next message to take
@@ -329,6 +329,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
     wave_sync();
 
     uint32_t tag = kNoWin;                             // per-lane window directory: lane s = slot s
+    uint32_t stale = 0;                                // per-lane: slot s was trained outside a two-wave section (p16 not current)
     uint32_t lastuse = 0;                              // per-lane: value of t after the last byte / message that used slot s
     uint32_t t = 0;                                    // bytes decoded + window swaps so far = messages published to wave B
     uint32_t h0 = 0;                                   // h[0] = z.H(0)
@@ -409,6 +410,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
           }
           ++t;
           lastuse = lane == slot ? t : lastuse;
+          stale = lane == slot ? 1u : stale;
           ZH_STAMP(1);
           // lane j of any quad: first-nibble node j; lane (q, j): node j of second-nibble groups q, q+4, q+8, q+12
           uint32_t *wa = &S.winA[slot][0], *wb = &S.winB[slot][0];
@@ -476,7 +478,8 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
         if (LIKELY(pp_state == 1)) {
           // ===== steady state: PASS post-processor (PostProcessor.cs:49-51), two wavefronts =====
           // hand the window cache and the output to wave B
-          S.tags[lane] = tag;
+          S.tags[lane] = stale;
+          stale = 0;
           if (lane < kRing) S.ring[lane] = ((ring_tag(t) + 64) & 127) << 25;   // never the tag of messages t .. t+15
           out_flush(ob, lane);
           if (lane == 0) {
