@@ -62,8 +62,15 @@ def gen(name, spec_id, header):
            f"  static constexpr uint32_t id = {spec_id}u, n = {n}u, types = 0x{types:x}u, nmix = {len(mixers)}u, depth = {max(lv)}u;",
            "};",
            "template <class LaneT>",
-           f"__device__ __forceinline__ void zh_spec_levels_{name}(LaneT &me, uint32_t lane, uint32_t c8, const int16_t *stretch, const uint8_t *arena) {{",
-           "  (void)c8; (void)stretch; (void)arena;"]
+           f"__device__ __forceinline__ void zh_spec_levels_{name}(LaneT &me, uint32_t lane, uint32_t c8, const int16_t *stretch, const uint8_t *arena, uint32_t *sserow) {{",
+           "  (void)c8; (void)stretch; (void)arena; (void)sserow;"]
+    # An SSE interpolates between two neighbours of the 32-entry row (h + c8) * 32 of its table; which two depends on its
+    # input, known only at its level — but the row is known now.  All lanes request it here (lane & 31 = entry), so that
+    # the HBM/L2 round trip runs under the levels before it; the entries are parked in LDS just before the level.
+    sses = [i for i, c in enumerate(comps) if c[0] == T["sse"]]
+    for k, i in enumerate(sses):
+        out.append(f"  const uint32_t sse_rb{i} = zhdev::rdlane(((me.h + c8) * 32u) & me.cm_mask, {i}u), sse_of{i} = zhdev::rdlane(me.cmo, {i}u);")
+        out.append(f"  const uint32_t sse_pre{i} = reinterpret_cast<const uint32_t *>(arena + sse_of{i})[sse_rb{i} + (lane & 31u)];")
     for level in range(1, max(lv) + 1):
         out.append(f"  // level {level}")
         for i, c in enumerate(comps):
@@ -89,14 +96,14 @@ def gen(name, spec_id, header):
                 out.append(f"    me.p = lane == {i}u ? v : me.p;")
             elif t == T["sse"]:
                 out.append("    " + operand("pj", c[2], i))
+                out.append(f"    sserow[{sses.index(i) * 32}u + (lane & 31u)] = sse_pre{i};            // the row requested at the top (every entry twice, same value)")
                 out.append(f"    if (lane == {i}u) {{                          // Predictor.cs:327-340")
                 out.append("      me.pj = pj;")
                 out.append("      me.cxt = (me.h + c8) * 32u;")
                 out.append("      int pq = pj + 992; pq = pq < 0 ? 0 : pq > 1983 ? 1983 : pq;")
                 out.append("      const int wt = pq & 63; pq >>= 6;")
                 out.append("      me.cxt += (uint32_t)pq;")
-                out.append("      const uint32_t *cm = reinterpret_cast<const uint32_t *>(arena + me.cmo);")
-                out.append("      const uint32_t e0 = cm[me.cxt & me.cm_mask], e1 = cm[(me.cxt + 1) & me.cm_mask];")
+                out.append(f"      const uint32_t e0 = sserow[{sses.index(i) * 32} + pq], e1 = sserow[{sses.index(i) * 32} + pq + 1];")
                 out.append("      me.p = stretch[((e0 >> 10) * (uint32_t)(64 - wt) + (e1 >> 10) * (uint32_t)wt) >> 13];")
                 out.append("      me.cxt += (uint32_t)(wt >> 5);")
                 out.append("      me.w0 = (int)((wt >> 5) ? e1 : e0);")

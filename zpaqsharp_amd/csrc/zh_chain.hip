@@ -52,6 +52,7 @@ struct alignas(16) ChainLds {
   ZhTables t;
   uint32_t small[kSmallWords];
   uint8_t slot[64][64];                   // per-lane nibble cache (hash row or CM line)
+  uint32_t sserow[64];                    // specialised kernels: the 32-entry table row of up to two SSE components for this bit
   uint32_t dummy[64];                     // per-lane sink for the stores of lanes a branch-free step does not concern
   uint32_t hreg[kHWords];
   uint8_t mreg[kMBytes];
@@ -459,9 +460,9 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             }
             ZH_STAMP(0);
             // ================= predict, dependent levels =================
-            if constexpr (SP::id == 1) zh_spec_levels_min(me, lane, c8, S.t.stretch, slot_mem);
-            else if constexpr (SP::id == 2) zh_spec_levels_mid(me, lane, c8, S.t.stretch, slot_mem);
-            else if constexpr (SP::id == 3) zh_spec_levels_max(me, lane, c8, S.t.stretch, slot_mem);
+            if constexpr (SP::id == 1) zh_spec_levels_min(me, lane, c8, S.t.stretch, slot_mem, S.sserow);
+            else if constexpr (SP::id == 2) zh_spec_levels_mid(me, lane, c8, S.t.stretch, slot_mem, S.sserow);
+            else if constexpr (SP::id == 3) zh_spec_levels_max(me, lane, c8, S.t.stretch, slot_mem, S.sserow);
             else {
             for (uint32_t lv = 1; lv <= depth; ++lv) {
               const uint32_t desc = rdlane(lvl_desc, lv & 63);
