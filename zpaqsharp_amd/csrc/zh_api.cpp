@@ -20,6 +20,7 @@
 
 extern "C" hipError_t zh_launch_generic(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
+extern "C" hipError_t zh_launch_sha1(const uint8_t *data, const uint64_t *seg, uint32_t n_seg, uint32_t *digest, hipStream_t stream);
 extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof);
 extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 
@@ -447,22 +448,45 @@ int decode_stream_to_device(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, co
   return ZPAQHIP_OK;
 }
 
-int verify_sha1(const ScanOut &so, const std::vector<zpaqhip_seg_result> &res, const uint8_t *out, zpaqhip_err *err) {
+// SHA-1 of every decoded segment that stores one, computed ON THE DEVICE over ctx->out (zh_sha1_dev.hip) while the
+// plaintext is still there; bad[s] = 1 where the digest differs from the stored one (Decompresser.cs:183-191).
+int sha1_mismatches(zpaqhip_ctx *c, const ScanOut &so, const std::vector<zpaqhip_seg_result> &res, std::vector<int> &bad,
+                    zpaqhip_err *err) {
   const size_t ns = so.segs.size();
-  std::vector<int> bad(ns, 0);
-  unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  std::vector<std::thread> th;
-  for (unsigned t = 0; t < nt; ++t)
-    th.emplace_back([&, t] {
-      for (size_t s = t; s < ns; s += nt) {
-        if (!(so.segs[s].flags & 1)) continue;
-        uint8_t d[20];
-        sha1(out + res[s].out_off, res[s].out_len, d);
-        bad[s] = memcmp(d, so.segs[s].sha1, 20) != 0;
-      }
-    });
-  for (auto &t : th) t.join();
-  for (size_t s = 0; s < ns; ++s)
+  bad.assign(ns, 0);
+  std::vector<uint64_t> tab;
+  std::vector<uint32_t> which;
+  for (size_t s = 0; s < ns; ++s) {
+    if (!(so.segs[s].flags & 1) || res[s].status != ZPAQHIP_OK) continue;
+    tab.push_back(res[s].out_off);
+    tab.push_back(res[s].out_len);
+    which.push_back((uint32_t)s);
+  }
+  if (which.empty()) return ZPAQHIP_OK;
+  const size_t tab_bytes = tab.size() * 8, dig_bytes = which.size() * 20;
+  HIPCHK(c->sdesc.reserve(tab_bytes + dig_bytes + 64));          // the descriptors of the finished decode are not needed any more
+  uint8_t *d_tab = (uint8_t *)c->sdesc.p, *d_dig = d_tab + ((tab_bytes + 15) & ~(size_t)15);
+  HIPCHK(hipMemcpyAsync(d_tab, tab.data(), tab_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(zh_launch_sha1((const uint8_t *)c->out.p, (const uint64_t *)d_tab, (uint32_t)which.size(), (uint32_t *)d_dig, c->stream));
+  std::vector<uint32_t> dig(which.size() * 5);
+  HIPCHK(hipMemcpyAsync(dig.data(), d_dig, dig_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (size_t k = 0; k < which.size(); ++k) {
+    uint8_t d[20];
+    for (int i = 0; i < 5; ++i) {
+      const uint32_t v = dig[5 * k + i];
+      d[4 * i] = (uint8_t)(v >> 24); d[4 * i + 1] = (uint8_t)(v >> 16); d[4 * i + 2] = (uint8_t)(v >> 8); d[4 * i + 3] = (uint8_t)v;
+    }
+    bad[which[k]] = memcmp(d, so.segs[which[k]].sha1, 20) != 0;
+  }
+  return ZPAQHIP_OK;
+}
+
+int verify_sha1(zpaqhip_ctx *c, const ScanOut &so, const std::vector<zpaqhip_seg_result> &res, zpaqhip_err *err) {
+  std::vector<int> bad;
+  int rc = sha1_mismatches(c, so, res, bad, err);
+  if (rc) return rc;
+  for (size_t s = 0; s < bad.size(); ++s)
     if (bad[s]) { set_err(err, ZPAQHIP_E_SHA1, (int)so.segs[s].block, (int)s); return ZPAQHIP_E_SHA1; }
   return ZPAQHIP_OK;
 }
@@ -483,6 +507,7 @@ int zpaqhip_decompress(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint8_t
   if (rc) return rc;
   *out_len = (size_t)total;
   if (total > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, -1, -1); return ZPAQHIP_E_OUTPUT_FULL; }
+  if (opts.verify_sha1) { rc = verify_sha1(c, so, res, err); if (rc) return rc; }      // on the device, before the copy back
   if (total) {
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     HIPCHK(hipMemcpyAsync(out, c->out.p, total, hipMemcpyDeviceToHost, c->stream));
@@ -492,7 +517,6 @@ int zpaqhip_decompress(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint8_t
     HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->stats.d2h_ms = ms;
   }
-  if (opts.verify_sha1) return verify_sha1(so, res, out, err);
   return ZPAQHIP_OK;
 }
 
@@ -517,12 +541,11 @@ int zpaqhip_decompress_segments(zpaqhip_ctx *c, const uint8_t *in, size_t in_len
   if (total > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, -1, -1); return ZPAQHIP_E_OUTPUT_FULL; }
   if (total) HIPCHK(hipMemcpy(out, c->out.p, total, hipMemcpyDeviceToHost));
   if (opts.verify_sha1) {                   // mismatches become per-segment statuses
-    for (size_t s = 0; s < res.size(); ++s) {
-      if (!(so.segs[s].flags & 1) || res[s].status != ZPAQHIP_OK) continue;
-      uint8_t d[20];
-      sha1(out + res[s].out_off, res[s].out_len, d);
-      if (memcmp(d, so.segs[s].sha1, 20)) results[s].status = ZPAQHIP_E_SHA1;
-    }
+    std::vector<int> bad;
+    rc = sha1_mismatches(c, so, res, bad, err);
+    if (rc) return rc;
+    for (size_t s = 0; s < res.size(); ++s)
+      if (bad[s]) results[s].status = ZPAQHIP_E_SHA1;
   }
   return ZPAQHIP_OK;
 }
@@ -593,7 +616,7 @@ int zpaqhip_decompress_cb(zpaqhip_ctx *c, zpaqhip_read_fn read_fn, zpaqhip_write
   if (rc) return rc;
   std::vector<uint8_t> out((size_t)total);
   if (total) HIPCHK(hipMemcpy(out.data(), c->out.p, total, hipMemcpyDeviceToHost));
-  if (opts.verify_sha1) { rc = verify_sha1(so, res, out.data(), err); if (rc) return rc; }
+  if (opts.verify_sha1) { rc = verify_sha1(c, so, res, err); if (rc) return rc; }
   for (size_t p = 0; p < out.size();) {                 // Writer.write (Writer.cs:19-24)
     int n = (int)std::min<size_t>(out.size() - p, 1 << 20);
     if (write_fn(user, out.data() + p, n) < 0) { set_err(err, ZPAQHIP_E_CALLBACK, -1, -1); return ZPAQHIP_E_CALLBACK; }
