@@ -113,7 +113,7 @@ typedef struct zpaqhip_seg_result {
 
 typedef struct zpaqhip_opts {
   uint32_t struct_size;       /* = sizeof(zpaqhip_opts) */
-  uint32_t verify_sha1;       /* 1: check stored SHA-1 of every segment (Decompresser.cs:183-191 contract) */
+  uint32_t verify_sha1;       /* 1: check stored SHA-1 of every segment (Decompresser.cs:183-191 contract); hashed on the GPU */
   uint32_t max_concurrent;    /* blocks in flight per launch; 0 = auto (memory-bound) */
   uint32_t kernel;            /* 0 auto; 1 force the generic (one-lane) kernel; 3 prefer the lane-per-component kernel;
                                  4 lane-per-component without model specialisation */
