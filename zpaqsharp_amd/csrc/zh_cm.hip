@@ -142,8 +142,16 @@ __device__ __forceinline__ uint32_t pick_victim(uint32_t tag, uint32_t lastuse, 
   const uint64_t empty = __ballot(tag == kNoWin);
   if (empty) return (uint32_t)__builtin_ctzll(empty);
   const uint32_t age = now - lastuse;
+  // wave-wide maximum with DPP row shifts / row broadcasts (same shape as zhdev::wave_sum); lane 63 ends up with it
   uint32_t m = age;
-  for (int d = 32; d; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)m, d); m = o > m ? o : m; }
+  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x111, 0xf, 0xf, false));   // row_shr:1
+  m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x112, 0xf, 0xf, false));   // row_shr:2
+  m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x114, 0xf, 0xf, false));   // row_shr:4
+  m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x118, 0xf, 0xf, false));   // row_shr:8
+  m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1,3
+  m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2,3
+  m = rdlane(m, 63);
   return (uint32_t)__builtin_ctzll(__ballot(age == m));
 }
 
@@ -240,8 +248,15 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
       } else if (type == kMsgMiss) {
         sp = 0;
         const uint32_t neww = uni(S.aux[u & (kRing - 1)][0]), oldw = uni(S.aux[u & (kRing - 1)][1]);
-        if (oldw != kNoWin) win_store(S, slot, table, oldw, lane);
-        win_load(S, slot, table, neww, lane);
+        {                                                  // request the new window first, write the victim back while it travels
+          const uint4 *g = reinterpret_cast<const uint4 *>(table + (uint64_t)neww * 512);
+          const uint4 nb = g[64 + lane];
+          uint4 na = make_uint4(0, 0, 0, 0);
+          if (lane < 4) na = g[lane];
+          if (oldw != kNoWin) win_store(S, slot, table, oldw, lane);
+          reinterpret_cast<uint4 *>(&S.winB[slot][0])[lane] = nb;
+          if (lane < 4) reinterpret_cast<uint4 *>(&S.winA[slot][0])[lane] = na;
+        }
         wave_sync();
         p16_rebuild(S, slot, lane);
         ++u;
