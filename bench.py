@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 # (derivation repeated in DESIGN.md §5).
 B_ALG = {"l1": 64, "min": 128, "mid": 842, "max": 3114}
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_COPY_GBPS = 6290.0          # same guide: measured copy peak (SURVEY.md §8d asks for both fractions)
 
 
 def pmc_traffic(model, nb, bs):
@@ -223,6 +224,7 @@ def main():
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS,
+                     "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
                      "traffic": (pmc_traffic(model_name, nb, bs) or {}).get("bytes"),
                      "traffic_source": (pmc_traffic(model_name, nb, bs) or {}).get("source"),
                      "algorithmic_bytes_per_launch": b_alg * plain_bytes,
