@@ -182,6 +182,18 @@ def test_many_small_segments_in_one_block(ctx):
         assert all(r.status == 0 for r in res[:len(parts)])
 
 
+@pytest.mark.parametrize("bits,shift", [(9, 9), (12, 31), (17, 16), (24, 13), (20, 9), (11, 12), (26, 18)])
+def test_single_cm_shift_forms(ctx, bits, shift):
+    """Every (table size, shift) the two-wave kernel takes — the window id is (byte << shift & mask) >> 9 — against the oracle."""
+    m = zpaql.assemble(f"comp 0 0 0 0 1 0 cm {bits} 255 hcomp a<<= {shift} *d=a halt end")
+    rng = np.random.default_rng(bits * 100 + shift)
+    data = util.text(20000, seed=shift) + bytes(rng.integers(0, 256, 6000, dtype=np.uint8)) + b"z" * 3000
+    s = synth.compress_block(m, data)
+    assert oracle.decompress(s) == data
+    assert ctx.decompress(s, verify_sha1=True).tobytes() == data
+    assert ctx.stats().kernel_kind == 2
+
+
 def test_multi_segment_blocks(ctx):
     for model in ("l1", "mid", "max+e8e9"):
         m = models.get(model)
