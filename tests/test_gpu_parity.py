@@ -194,6 +194,29 @@ def test_single_cm_shift_forms(ctx, bits, shift):
     assert ctx.stats().kernel_kind == 2
 
 
+def test_two_contexts_in_two_threads():
+    """A context is single-threaded, distinct contexts are independent (LICENSE:44-46; include/zpaqhip.h)."""
+    import threading
+    streams = [synth.stream(m, "T", nblocks=24, block_size=60000, first_block=100 * i, threads=2)[0] for i, m in enumerate(("l1", "mid"))]
+    want = [oracle.decompress(s.tobytes(), cap=24 * 60000 + 16) for s in streams]
+    got, errs = [None, None], []
+
+    def work(i):
+        try:
+            c = z.Context(0)
+            for _ in range(3):
+                got[i] = c.decompress(streams[i], verify_sha1=True).tobytes()
+            c.close()
+        except BaseException as e:                       # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert got == want
+
+
 def test_multi_segment_blocks(ctx):
     for model in ("l1", "mid", "max+e8e9"):
         m = models.get(model)
