@@ -404,6 +404,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
           int pmw[kMaxMix] = {0, 0, 0, 0};
           for (int bit = 0; bit < 8; ++bit) {
             if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
+            c8 = uni(c8); hmap4 = uni(hmap4);
             const uint32_t hm15 = hmap4 & 15;
             // ================= predict, level 0 (Predictor.cs:259-343) =================
             uint32_t rows[kMaxMix] = {0, 0, 0, 0};
@@ -543,7 +544,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             const uint32_t ps = (pr * 2 + 1) << 16;
             ZH_DEC_STEP(d, ps, j, bad, rn);
             if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane) && !err) err = bad ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF; }
-            const int y = (int)(j & 1);
+            const int y = (int)uni(j & 1);
 
             ZH_STAMP(2);
             // ================= update (Predictor.cs:363-461) =================
@@ -589,13 +590,14 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             }
             ZH_STAMP(3);
             // ---- c8 / hmap4 bookkeeping (Predictor.cs:463-474)
-            c8 = c8 * 2 + (uint32_t)y;
+            c8 = uni(c8 * 2 + (uint32_t)y);                 // pinned to the scalar unit: LLVM's uniformity analysis otherwise
+                                                            // treats the byte state as divergent and runs this loop on exec masks
             if (c8 >= 256) break;                        // byte complete: handled below
             if (c8 >= 16 && c8 < 32) {
-              hmap4 = (hmap4 & 0xf) << 5 | (uint32_t)y << 4 | 1;
+              hmap4 = uni((hmap4 & 0xf) << 5 | (uint32_t)y << 4 | 1);
               nibble_refresh();
               ZH_STAMP(4);
-            } else hmap4 = (hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + (uint32_t)y) & 0xf);
+            } else hmap4 = uni((hmap4 & 0x1f0) | (((hmap4 & 0xf) * 2 + (uint32_t)y) & 0xf));
           }
           if (UNLIKELY(err | bad)) { status = err ? -(int)err : ZH_E_CORRUPT; break; }
           c = (int)(c8 - 256);
