@@ -209,12 +209,20 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 // In-kernel stamps (diagnostic build only: *_prof kernels): cycles spent per
 // stage of a byte, summed per block and added to L.debug[stage].
+// ZH_STAMP_WAIT: what a stamp drains first.  Default: everything (a stage pays for its own memory latency);
+// make CXXFLAGS+=-DZH_STAMP_NOVM leaves global memory operations in flight (stages are charged the way the
+// non-diagnostic build runs them).
+#if defined(ZH_STAMP_NOVM)
+#define ZH_STAMP_WAIT "s_waitcnt lgkmcnt(0)"
+#else
+#define ZH_STAMP_WAIT "s_waitcnt vmcnt(0) lgkmcnt(0)"
+#endif
 #define ZH_STAMP(i)                                                              \
   do {                                                                           \
     if (PROF) {                                                                  \
       uint64_t now_;                                                             \
       __builtin_amdgcn_sched_barrier(0);                                         \
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+      asm volatile(ZH_STAMP_WAIT "\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
       __builtin_amdgcn_sched_barrier(0);                                         \
       prof[i] += now_ - tprev;                                                   \
       tprev = now_;                                                              \
