@@ -534,10 +534,10 @@ def test_kernel_selection_and_cross_kernel_agreement(ctx, model, kind):
 def test_random_component_chains(ctx):
     """Random COMP lists exercising every component type and arbitrary input wiring on the
     lane-per-component kernel, against the oracle (encoder: libzpaqgen, decoder: oracle + GPU)."""
-    rng = np.random.default_rng(12345)
+    rng = np.random.default_rng(int(os.environ.get("ZPAQ_FUZZ_SEED", "12345")))
     data = util.text(6000, seed=21) + util.x86ish(2000, seed=22)
     hcomp = "c++ *c=a b=c a=0 d= 0 hash *d=a b-- d++ hash *d=a b-- d++ hash *d=a d++ a=*c a<<= 8 *d=a d++ a=*c a*= 200 *d=a halt"
-    for trial in range(12):
+    for trial in range(int(os.environ.get("ZPAQ_FUZZ_TRIALS", "12"))):
         n = int(rng.integers(2, 12))
         comps = []
         for i in range(n):
