@@ -229,7 +229,7 @@ def main():
                      "traffic_source": (pmc_traffic(model_name, nb, bs) or {}).get("source"),
                      "algorithmic_bytes_per_launch": b_alg * plain_bytes,
                      "kernel_ms": kms, "alg_bytes_per_plain_byte": b_alg,
-                     "note": "latency-bound bit-serial chain; see DESIGN.md §5"},
+                     "note": "bit-serial chain bound by single-wave instruction issue, not by HBM; see DESIGN.md §4"},
         "cpu_baseline": cpu,
         "gen_seconds": round(gen_s, 1),
     }
