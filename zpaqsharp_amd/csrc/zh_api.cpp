@@ -66,6 +66,8 @@ namespace {
     }                                                                         \
   } while (0)
 
+constexpr uint64_t kPpOnlyMagic = 0x5A50505F4F4E4C59ull;   // internal: zpaqhip_block_pcomp -> decode_blocks_device ("ZPP_ONLY")
+
 zpaqhip_opts resolve_opts(const zpaqhip_opts *o) {
   zpaqhip_opts r;
   memset(&r, 0, sizeof r);
@@ -314,6 +316,7 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     L.queue = (uint32_t *)c->queue.p + 8 * g;           // one work-queue head per launch
     L.n_blocks = (uint32_t)groups[g].size();
     L.budget = opts.zpaql_budget;
+    L.flags = opts.reserved[0] == kPpOnlyMagic ? ZH_LAUNCH_PP_ONLY : 0u;
     const bool prof = getenv("ZPAQHIP_PROF") != nullptr;   // diagnostic build with in-kernel stamps
     if (prof) { L.debug = (uint64_t *)c->queue.p + 16; HIPCHK(hipMemsetAsync(L.debug, 0, 64, stream)); }
     if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, slots_of[g], stream));
@@ -346,6 +349,7 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     const zpaqhip_block &b = blocks[sel[k]];
     for (uint32_t s = 0; s < b.n_seg; ++s) {
       const uint32_t si = b.first_seg + s;
+      if (res[si].status == ZH_E_STOPPED) res[si].status = ZPAQHIP_OK, res[si].in_used = segs[si].data_len;   // ended on request
       results[si].status = res[si].status;
       results[si].pp_state = res[si].pp_state & 255u;
       c->raw_pp[si] = res[si].pp_state;
@@ -552,8 +556,8 @@ int zpaqhip_decompress_segments(zpaqhip_ctx *c, const uint8_t *in, size_t in_len
 
 // Decompresser.pcomp (Decompresser.cs:155-158 -> ZPAQL.write(out, true), ZPAQL.cs:158-179): the PCOMP program a block's
 // first segment carries, as "length lo, length hi, program bytes"; *out_len = 0 when the block has none.  The program
-// travels inside the coded data, so the block is decoded (counting only, one arena slot) and the program is read back
-// from that slot.
+// travels inside the coded data, so the start of the block is decoded (the generic kernel stops once the post-processor
+// header is complete) and the program is read back from the arena slot.
 int zpaqhip_block_pcomp(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint32_t block, uint8_t *out, size_t out_cap,
                         size_t *out_len, zpaqhip_err *err) {
   if (!c || (!in && in_len) || !out_len || (!out && out_cap)) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
@@ -572,6 +576,8 @@ int zpaqhip_block_pcomp(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint32
   memset(&o, 0, sizeof o);
   o.struct_size = sizeof o;
   o.max_concurrent = 1;                                  // the block runs in arena slot 0
+  o.kernel = 1;                                          // the generic kernel knows how to stop after the header
+  o.reserved[0] = kPpOnlyMagic;
   std::vector<zpaqhip_seg_result> res(so.segs.size());
   const uint32_t id = block;
   const uint64_t off0 = 0, cap0 = 0;                     // count-only: nothing is written
@@ -580,7 +586,8 @@ int zpaqhip_block_pcomp(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint32
   const uint32_t raw = c->raw_pp.size() > b.first_seg ? c->raw_pp[b.first_seg] : 0;
   const uint32_t state = raw & 255u, hsize = raw >> 8;
   if (state < 5) {                                       // PASS, or the stream broke before the program was complete
-    if (rc && rc != ZPAQHIP_E_OUTPUT_FULL && res[b.first_seg].status != ZPAQHIP_OK && res[b.first_seg].status != ZPAQHIP_E_OUTPUT_FULL) return rc;
+    const int st0 = res[b.first_seg].status;
+    if (rc && st0 != ZPAQHIP_OK && st0 != ZPAQHIP_E_OUTPUT_FULL) return rc;
     return ZPAQHIP_OK;
   }
   *out_len = (size_t)hsize + 2;

@@ -280,6 +280,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_generic(ZhLaunch L) {
           int rc = pp_write(pp, c, out, M, slot, L.budget);
           if (rc) { status = rc; break; }
           if (c == -1) break;
+          if ((L.flags & ZH_LAUNCH_PP_ONLY) && (pp.state == 1 || pp.state == 5)) { status = ZH_E_STOPPED; break; }   // pcomp() read-back
         }
         if (!status && out.len > out.cap) status = ZH_E_OUTPUT_FULL;
         if (status && status != ZH_E_OUTPUT_FULL) failed = 1;

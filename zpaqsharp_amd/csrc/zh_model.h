@@ -42,6 +42,8 @@ enum ZhCompType : uint8_t {  // LibZPAQ.cs:51-63
 #define ZH_E_OUTPUT_FULL (-20)
 #define ZH_E_BUDGET (-26)
 #define ZH_E_SKIPPED (-100)       // an earlier segment of the block failed
+#define ZH_E_STOPPED (-101)       // decode ended on request (ZH_LAUNCH_PP_ONLY); never leaves the library
+#define ZH_LAUNCH_PP_ONLY 1u
 
 struct ZhComp {            // one component of a model (Component.cs:18-57 + header args)
   uint8_t type;            // ZhCompType
@@ -110,7 +112,7 @@ struct ZhLaunch {          // kernel arguments (one struct, passed by value)
   const ZhTables *tables;
   uint32_t *queue;         // work-queue head (device-scope atomic)
   uint32_t n_blocks;
-  uint32_t pad;
+  uint32_t flags;          // ZH_LAUNCH_PP_ONLY: stop a block once its post-processor header is complete (generic kernel)
   uint64_t budget;         // ZPAQL instructions per run()
   uint64_t in_total;       // length of the whole stream at `in`
   uint64_t *debug;         // diagnostic builds only (cycle sums); NULL otherwise
