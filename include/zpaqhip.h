@@ -215,7 +215,7 @@ int zpaqhip_read_device_tables(zpaqhip_ctx *ctx, uint16_t *squash, int16_t *stre
  * program of block `block` (index into zpaqhip_scan's table) as the reference writes it: length low byte, length
  * high byte, program bytes.  *out_len = 0 and ZPAQHIP_OK when the block has no PCOMP (pcomp() returns false).
  * ZPAQHIP_E_OUTPUT_FULL with *out_len = bytes needed when out_cap is too small.  The program is part of the coded
- * data, so this call decodes the block (nothing is written anywhere) before it can answer. */
+ * data: this call decodes the first bytes of the block (up to the end of the post-processor header) on the GPU. */
 int zpaqhip_block_pcomp(zpaqhip_ctx *ctx, const uint8_t *in, size_t in_len, uint32_t block,
                         uint8_t *out, size_t out_cap, size_t *out_len, zpaqhip_err *err);
 
