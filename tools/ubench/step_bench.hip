@@ -73,6 +73,28 @@
   "v_readlane_b32 s95, %[pv], %[j]\n\t" CORE("s94") SEL TAIL \
   CORE("s94") SPLIT TAIL
 
+// ... versus the same per-step fetch issued as soon as the node index is known (j is updated right after the
+// compare; the bit is then recovered from j for the two selects), alternating two probability registers
+#define STEP_C(PCUR, PNEXT)                    \
+  "s_sub_u32 s84, %[high], %[low]\n\t"         \
+  "s_sub_u32 s85, %[curr], %[low]\n\t"         \
+  "s_mul_hi_u32 s86, s84, " PCUR "\n\t"        \
+  "s_add_u32 s87, %[low], s86\n\t"             \
+  "s_add_u32 s88, s87, 1\n\t"                  \
+  "s_cmp_le_u32 s85, s86\n\t"                  \
+  "s_addc_u32 %[j], %[j], %[j]\n\t"            \
+  "v_readlane_b32 " PNEXT ", %[pv], %[j]\n\t"  \
+  "s_bitcmp1_b32 %[j], 0\n\t"                  \
+  "s_cselect_b32 %[high], s87, %[high]\n\t"    \
+  "s_cselect_b32 %[low], %[low], s88\n\t"      \
+  "s_xor_b32 s84, %[high], %[low]\n\t"         \
+  "s_cmp_lt_u32 s84, 0x100\n\t"                \
+  "s_cbranch_scc1 9f\n\t"
+#define NIB_C                                  \
+  "s_mov_b32 %[j], 1\n\t"                      \
+  "v_readlane_b32 s94, %[pv], %[j]\n\t"        \
+  STEP_C("s94", "s95") STEP_C("s95", "s94") STEP_C("s94", "s95") STEP_C("s95", "s94")
+
 __global__ void k(uint64_t *out, uint32_t seed, int spin) {
   __shared__ uint32_t flag[4];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -117,6 +139,13 @@ __global__ void k(uint64_t *out, uint32_t seed, int spin) {
                  : "scc", "s84", "s85", "s86", "s87", "s88", "s94", "s95", "s96");
     STAMP(t1); out[n++] = t1 - t0;
   }
+  low = 1; high = 0xFFFFFFF0u;
+  for (int rep = 0; rep < 2; ++rep) {
+    STAMP(t0);
+    asm volatile(REP4(NIB_C) "9:\n\t" : [low] "+s"(low), [high] "+s"(high), [curr] "+s"(curr), [j] "+s"(j) : [pv] "v"(pv)
+                 : "scc", "s84", "s85", "s86", "s87", "s88", "s94", "s95", "s96");
+    STAMP(t1); out[n++] = t1 - t0;
+  }
   // pieces
   STAMP(t0);
   asm volatile(REP16("v_readlane_b32 s94, %[pv], %[j]\n\ts_add_u32 %[j], s94, 1\n\ts_and_b32 %[j], %[j], 63\n\t") : [j] "+s"(j) : [pv] "v"(pv) : "scc", "s94");
@@ -136,7 +165,7 @@ __global__ void k(uint64_t *out, uint32_t seed, int spin) {
 int main() {
   uint64_t *d;
   hipMalloc(&d, 256);
-  const char *names[] = {"STEP x16 (cold)", "STEP x16", "STEP2 x16 (cold)", "STEP2 x16", "4 nibbles, readlane per step (cold)", "4 nibbles, readlane per step", "4 nibbles, children pairs (cold)", "4 nibbles, children pairs", "readlane->2 salu x16 (48)", "mul_hi->add x16 (32)",
+  const char *names[] = {"STEP x16 (cold)", "STEP x16", "STEP2 x16 (cold)", "STEP2 x16", "4 nibbles, readlane per step (cold)", "4 nibbles, readlane per step", "4 nibbles, children pairs (cold)", "4 nibbles, children pairs", "4 nibbles, early fetch (cold)", "4 nibbles, early fetch", "readlane->2 salu x16 (48)", "mul_hi->add x16 (32)",
                          "cmp->cselect x16 (32)", "empty stamp pair"};
   for (int spin = 0; spin < 2; ++spin) {
     for (int rep = 0; rep < 2; ++rep) {
@@ -146,7 +175,7 @@ int main() {
     uint64_t o[32];
     hipMemcpy(o, d, 256, hipMemcpyDeviceToHost);
     printf("second wave: %s\n", spin == 0 ? "exits at once" : spin == 1 ? "polls LDS flat out" : "polls LDS with s_sleep 2");
-    for (int i = 0; i < 12; ++i) printf("  %-32s %6llu cycles\n", names[i], (unsigned long long)o[i]);
+    for (int i = 0; i < 14; ++i) printf("  %-32s %6llu cycles\n", names[i], (unsigned long long)o[i]);
   }
   return 0;
 }
