@@ -72,6 +72,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--gen-threads", type=int, default=None)
+    ap.add_argument("--cache-dir", default=None, help="keep generated streams here and reuse them (profiling runs)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; the real thing) | gloo (rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: ranks share the visible GPUs round-robin (needs --dist-backend gloo)")
@@ -117,7 +118,15 @@ def main():
     ncpu = os.cpu_count() or 1
     gen_threads = args.gen_threads or max(1, min(32, ncpu // max(1, min(world, 8))))
     t0 = time.time()
-    stream, offs = synth.stream(model, kind, nb, bs, first_block=rank * nb, threads=gen_threads)
+    cache = os.path.join(args.cache_dir, f"{model_name}_{kind}_{nb}x{bs}_r{rank}.npz") if args.cache_dir else None
+    if cache and os.path.exists(cache):
+        with np.load(cache) as f:
+            stream, offs = f["stream"], f["offs"]
+    else:
+        stream, offs = synth.stream(model, kind, nb, bs, first_block=rank * nb, threads=gen_threads)
+        if cache:
+            os.makedirs(args.cache_dir, exist_ok=True)
+            np.savez(cache, stream=stream, offs=offs)
     gen_s = time.time() - t0
     sc = z.scan(stream)
     assert sc.n_blocks == nb, (sc.n_blocks, nb)

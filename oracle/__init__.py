@@ -63,6 +63,7 @@ def lib():
         L.zo_enc_start_block.argtypes = [vp, vp, sz]
         L.zo_enc_start_segment.argtypes = [vp, C.c_char_p, C.c_char_p]
         L.zo_enc_post_process.argtypes = [vp, vp, sz]
+        L.zo_enc_begin_raw.argtypes = [vp]
         L.zo_enc_compress.argtypes = [vp, vp, sz]
         L.zo_enc_end_segment.argtypes = [vp, vp]
         L.zo_enc_end_block.argtypes = [vp]
@@ -245,6 +246,10 @@ class Compressor:
 
     def post_process(self, pcomp: bytes = b""):
         self._chk(self._L.zo_enc_post_process(self._e, _buf(pcomp) if pcomp else None, len(pcomp)))
+
+    def begin_raw(self):
+        """Open the coder without a post-processor selector: the next compress() bytes are what PostProcessor.write sees."""
+        self._chk(self._L.zo_enc_begin_raw(self._e))
 
     def compress(self, data: bytes):
         self._chk(self._L.zo_enc_compress(self._e, _buf(data), len(data)))

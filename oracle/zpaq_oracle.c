@@ -748,8 +748,8 @@ static inline int dec_decode(decoder_t *d, int p) {
 /* Decoder.cs:32-68 */
 static int dec_decompress(decoder_t *d) {
   if (pred_is_modeled(&d->pr)) {
-    if (d->curr == 0)
-      for (int i = 0; i < 4; ++i) d->curr = d->curr << 8 | (U32)(rd_get(&d->in) & 255);
+    if (d->curr == 0)   /* get() == -1 at EOF sets all 32 bits, as the int -> U32 conversion of Decoder.cs:38-39 does */
+      for (int i = 0; i < 4; ++i) d->curr = d->curr << 8 | (U32)rd_get(&d->in);
     if (dec_decode(d, 0)) {
       if (d->curr != 0) zerror(d->err, "decoding end of stream");
       return -1;
@@ -765,7 +765,7 @@ static int dec_decompress(decoder_t *d) {
     return c - 256;
   } else {
     if (d->curr == 0) {
-      for (int i = 0; i < 4; ++i) d->curr = d->curr << 8 | (U32)(rd_get(&d->in) & 255);
+      for (int i = 0; i < 4; ++i) d->curr = d->curr << 8 | (U32)rd_get(&d->in);   /* Decoder.cs:62: EOF -> all ones */
       if (d->curr == 0) return -1;
     }
     --d->curr;
@@ -1124,6 +1124,20 @@ int zo_enc_post_process(zo_enc *e, const U8 *pcomp, size_t len) {
     enc_compress(e, (int)((len >> 8) & 255));
     for (size_t i = 0; i < len; ++i) enc_compress(e, pcomp[i]);
   } else enc_compress(e, 0);
+  e->state = 4;
+  DONE(e, 0);
+}
+
+/* Test hook (no reference counterpart): starts the coder of a segment like postProcess does but emits no
+ * post-processor selector, so that the caller's bytes ARE the decoded stream PostProcessor.write sees
+ * (malformed selectors, truncated PCOMP headers: PostProcessor.cs:43-68). */
+int zo_enc_begin_raw(zo_enc *e) {
+  GUARD(e);
+  if (e->state == 4) DONE(e, 0);
+  if (e->state != 2) zerror(&e->err, "oracle: begin_raw out of order");
+  e->low = 1; e->high = 0xFFFFFFFFu;
+  pred_init(&e->pr);
+  if (!pred_is_modeled(&e->pr)) zerror(&e->err, "oracle: unmodelled (n=0) encode not supported");
   e->state = 4;
   DONE(e, 0);
 }

@@ -77,6 +77,8 @@ int zo_enc_start_block(zo_enc *, const uint8_t *hdr, size_t hdrlen);
 int zo_enc_start_segment(zo_enc *, const char *filename, const char *comment);
 /* pcomp==NULL/len 0 → PASS (0); else PROG (1, len lo, len hi, bytes). */
 int zo_enc_post_process(zo_enc *, const uint8_t *pcomp, size_t len);
+/* test hook: open the segment's coder without writing a post-processor selector (the caller encodes it) */
+int zo_enc_begin_raw(zo_enc *);
 int zo_enc_compress(zo_enc *, const uint8_t *data, size_t n);
 int zo_enc_end_segment(zo_enc *, const uint8_t sha1[20] /* or NULL */);
 int zo_enc_end_block(zo_enc *);

@@ -92,7 +92,7 @@ def test_cm_models_with_other_shapes(ctx):
         s = synth.compress_block(m, data)
         assert oracle.decompress(s) == data
         assert ctx.decompress(s, verify_sha1=True).tobytes() == data
-    m = zpaql.assemble("comp 0 0 0 3 1 0 cm 17 255 hcomp a<<= 9 *d=a halt " + models.E8E9_PCOMP.strip())
+    m = zpaql.assemble("comp 0 0 0 0 1 0 cm 17 255 hcomp a<<= 9 *d=a halt " + models.E8E9_PCOMP.strip())
     x = util.x86ish(20000, seed=5)
     s = synth.compress_block(m, x)
     assert oracle.decompress(s) == x

@@ -66,6 +66,7 @@ namespace {
     }                                                                         \
   } while (0)
 
+constexpr size_t kQueueBytes = 256, kDebugBytes = 64;    // work-queue heads (32 B per family) and the *_prof kernels' sums
 constexpr uint64_t kPpOnlyMagic = 0x5A50505F4F4E4C59ull;   // internal: zpaqhip_block_pcomp -> decode_blocks_device ("ZPP_ONLY")
 
 zpaqhip_opts resolve_opts(const zpaqhip_opts *o) {
@@ -263,12 +264,13 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
   HIPCHK(c->bdesc.reserve(sel.size() * sizeof(ZhBlockDesc)));
   HIPCHK(c->sdesc.reserve(sd.size() * sizeof(ZhSegDesc)));
   HIPCHK(c->results.reserve(n_segs * sizeof(ZhSegResult)));
-  HIPCHK(c->queue.reserve(256));
+  static_assert(32 * ZH_NFAM <= kQueueBytes, "one 32-byte work-queue head per kernel family");
+  HIPCHK(c->queue.reserve(kQueueBytes + kDebugBytes));   // [heads | diagnostic cycle sums]: the two never overlap
   HIPCHK(hipMemcpyAsync(c->models.p, models.data(), models.size() * sizeof(ZhModel), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(c->code.p, code.data(), code.size(), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(c->sdesc.p, sd.data(), sd.size() * sizeof(ZhSegDesc), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemsetAsync(c->results.p, 0xff, n_segs * sizeof(ZhSegResult), stream));
-  HIPCHK(hipMemsetAsync(c->queue.p, 0, 256, stream));
+  HIPCHK(hipMemsetAsync(c->queue.p, 0, kQueueBytes + kDebugBytes, stream));
 
   // arena: sized for the most demanding group
   uint32_t slots_of[ZH_NFAM] = {};
@@ -318,7 +320,7 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     L.budget = opts.zpaql_budget;
     L.flags = opts.reserved[0] == kPpOnlyMagic ? ZH_LAUNCH_PP_ONLY : 0u;
     const bool prof = getenv("ZPAQHIP_PROF") != nullptr;   // diagnostic build with in-kernel stamps
-    if (prof) { L.debug = (uint64_t *)c->queue.p + 16; HIPCHK(hipMemsetAsync(L.debug, 0, 64, stream)); }
+    if (prof) L.debug = (uint64_t *)((uint8_t *)c->queue.p + kQueueBytes);
     if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, slots_of[g], stream));
     else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, slots_of[g], stream));
     else if (g >= ZH_FAM_CHAIN) HIPCHK(zh_launch_chain(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));
@@ -331,7 +333,7 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
   if (getenv("ZPAQHIP_PROF")) {
     uint64_t dbg[8];
     HIPCHK(hipStreamSynchronize(stream));
-    HIPCHK(hipMemcpy(dbg, (uint64_t *)c->queue.p + 16, 64, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dbg, (uint8_t *)c->queue.p + kQueueBytes, 64, hipMemcpyDeviceToHost));
     fprintf(stderr, "ZPAQHIP_PROF cycles:");
     for (int i = 0; i < 8; ++i) fprintf(stderr, " %llu", (unsigned long long)dbg[i]);
     fprintf(stderr, "\n");

@@ -7,9 +7,9 @@ distribution calls them min.cfg / mid.cfg / max.cfg).  They are kept here as
 reference's hsize (26 / 69 / 196) and header CRCs.
 
 `l1` is the build-defined smallest modelled stream of BASELINE.json configs 1-2
-(SURVEY.md §8d): one direct order-1 CM.  `e8e9` is this repo's own ZPAQL
-post-processor that inverts the reference's forward E8E9 transform
-(LibZPAQ.cs:372-384); BASELINE.json config 5 = `max` model + this PCOMP.
+(SURVEY.md §8d): one direct order-1 CM.  `e8e9` is the reference's E8E9
+post-processor program (LibZPAQ.cs:802-826), the inverse of its forward
+transform (LibZPAQ.cs:372-384); BASELINE.json config 5 = `max` model + this PCOMP.
 """
 from __future__ import annotations
 
@@ -110,32 +110,32 @@ hcomp
 end
 """
 
-# Inverse E8E9 as a streaming ZPAQL program (own implementation).  M is an
-# 8-byte ring of the most recent input bytes, C counts bytes of the segment.
-# A byte is emitted 4 bytes late, after the 5-byte window starting at it has
-# been tested for (E8|E9) x x x (00|FF) and, on a match, its 24-bit little
-# endian operand has had the window's offset subtracted again.
+# The reference's E8E9 post-processor, as its config text (makeConfig, LibZPAQ.cs:802-826, emitted for methods whose
+# args[1] is 4: "pcomp e8e9 d ;").  It inverts the forward transform e8e9() of LibZPAQ.cs:372-384.  B is a shift
+# register of the last 4 input bytes, the byte shifted out of it is parked in M[0] (ph = pm = 0: M has one byte), C
+# counts the bytes held back (<= 4 pending at any time; flushed at EOF, a > 255).
 E8E9_PCOMP = """
-pcomp e8e9inv ;
-  a> 255 if                      (EOF: flush the pending min(c,4) bytes)
-    a=c a> 4 if a= 4 endif d=a
-    a=c a-=d b=a
-    do a=d a> 0 if
-      a=*b out b++ d--
-    forever endif
-    c=0
-  else
-    *c=a c++
+pcomp e8e9 d ;
+  a> 255 if
     a=c a> 4 if
-      b=c b-- a=*b a++ a&= 254 a== 0 if        (5th byte is 00 or FF)
-        a=c a-= 5 b=a
-        a=*b a&= 254 a== 232 if                (1st byte is E8 or E9)
-          b++ b++ b++ a=*b a<<= 8 b-- a|=*b a<<= 8 b-- a|=*b
-          a-=c a+= 5                           (minus the window offset c-5)
-          *b=a a>>= 8 b++ *b=a a>>= 8 b++ *b=a
+      c= 4
+    else
+      a! a+= 5 a<<= 3 d=a a=b a>>=d b=a
+    endif
+    do a=c a> 0 if
+      a=b out a>>= 8 b=a c--
+    forever endif
+  else
+    *b=b a<<= 24 d=a a=b a>>= 8 a+=d b=a c++
+    a=c a> 4 if
+      a=*b out
+      a&= 254 a== 232 if
+        a=b a>>= 24 a++ a&= 254 a== 0 if
+          a=b a>>= 24 a<<= 24 d=a
+          a=b a-=c a+= 5
+          a<<= 8 a>>= 8 a|=d b=a
         endif
       endif
-      a=c a-= 5 b=a a=*b out
     endif
   endif
   halt
@@ -202,7 +202,7 @@ def get(name: str) -> Model:
     if post == "":
         return assemble(cfg)
     if post == "e8e9":
-        return assemble(_with_pcomp(cfg, E8E9_PCOMP, pm=3))
+        return assemble(_with_pcomp(cfg, E8E9_PCOMP, pm=0))
     if post == "lz77":
         return assemble(_with_pcomp(cfg, LZ77_PCOMP, pm=16))
     raise KeyError(name)
