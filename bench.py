@@ -72,6 +72,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--gen-threads", type=int, default=None)
+    ap.add_argument("--kernel", type=int, default=0, help="zpaqhip_opts.kernel (0 auto; 5 = round-1 chain kernels for min/mid/max)")
     ap.add_argument("--cache-dir", default=None, help="keep generated streams here and reuse them (profiling runs)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; the real thing) | gloo (rehearsal of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -150,7 +151,7 @@ def main():
 
     def step():
         rc, res = ctx.decode_blocks_device(d_in.data_ptr(), stream.size, sc, d_out.data_ptr(), out_off, out_cap,
-                                           h_in=stream)
+                                           h_in=stream, kernel=args.kernel)
         return res
 
     def barrier():

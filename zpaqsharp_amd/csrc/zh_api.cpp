@@ -23,6 +23,8 @@ extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, uint32_t grid, hipStream_t
 extern "C" hipError_t zh_launch_sha1(const uint8_t *data, const uint64_t *seg, uint32_t n_seg, uint32_t *digest, hipStream_t stream);
 extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof);
 extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
+extern "C" hipError_t zh_launch_chain2(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec);
+extern "C" int zh_chain2_has(uint32_t spec);
 
 
 using namespace zh;
@@ -323,6 +325,8 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     if (prof) L.debug = (uint64_t *)((uint8_t *)c->queue.p + kQueueBytes);
     if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, slots_of[g], stream));
     else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, slots_of[g], stream));
+    else if (g > ZH_FAM_CHAIN && zh_chain2_has(g - ZH_FAM_CHAIN) && opts.kernel != 5 && !prof)   // per-model bit loop (zh_chain2.hip)
+      HIPCHK(zh_launch_chain2(&L, slots_of[g], stream, g - ZH_FAM_CHAIN));
     else if (g >= ZH_FAM_CHAIN) HIPCHK(zh_launch_chain(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));
     else HIPCHK(zh_launch_generic(&L, slots_of[g], stream));
     ++launches;

@@ -1,0 +1,633 @@
+// zh_chain2.hip — the bit loop of the reference's three built-in models (min / mid / max, Compressor.cs:48-74),
+// written per model for one gfx950 wavefront.  It replaces the model-specialised instances of zh_chain.hip; that
+// file stays as the kernel for any other component chain (and as the cross-check, opts.kernel = 5).
+//
+// The reference specialises the predictor per block header at run time by emitting x86 code
+// (Predictor.assemble_p, Predictor.cs:579-1356).  The analogue here is ahead-of-time: the host selects this kernel
+// only on an exact match of the header's COMP section (zh_chain_spec.h, zh_spec_lookup).
+//
+// What is different from zh_chain.hip (same lane-per-component mapping, same results):
+//
+//  * ONE-BIT-AHEAD, BOTH-WAYS FETCH.  Inside a nibble the node after j is 2j or 2j+1, and the bit histories of those two
+//    nodes are ADJACENT bytes of the hash row (Predictor.cs:269-272: ht[c + (hmap4 & 15)]).  While bit k is being
+//    predicted and decoded, every ICM / ISSE lane reads that byte pair and both table entries it selects; when y is
+//    known the right one is picked with a v_cndmask.  The only way bit k can change what bit k+1 reads is by training
+//    the very entry bit k+1 uses (same bit-history state); that case is detected by comparing entry addresses and
+//    served from the registers update() has just computed.  The dependent LDS walk (row byte -> table entry ->
+//    stretch) that cost ~670 cycles per bit in zh_chain.hip is off the critical path for 6 of the 8 bits of a byte.
+//    Mixer weight rows (Predictor.cs:302-316) are fetched the same way: rows c8*2 and c8*2+1 while bit c8 is decoded.
+//  * An ICM entry carries its stretched probability next to it ({cm, stretch(cm >> 8)}, 8 bytes like an ISSE's weight
+//    pair), maintained by update(): predict needs no table walk for it.
+//  * The ISSE chain (each ISSE takes the prediction of the component before it) is a SYSTOLIC step executed by all
+//    lanes: p <- clamp2k((w0 * p[lane-1] + w1x) >> 16), one DPP row_shr:1 multiply, one add, one shift, one med3.
+//    Lanes that are not an ISSE run it with w0 = 0 and w1x = p << 16, which reproduces p, so there is no per-level
+//    lane select; after `depth` steps every lane holds its final value.
+//  * All arena traffic goes through buffer instructions: 32-bit lane offset + scalar row offset, lanes that have
+//    nothing to load or store carry an out-of-range offset and are dropped by the range check (no exec-mask code).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "zh_core.h"
+#include "zh_dev.h"
+#include "zh_model.h"
+#include "zh_zpaql_native.h"
+
+using namespace zhcore;
+using namespace zhdev;
+
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+
+namespace {
+
+// ---- compile-time description of the three models (lane = component index) --------------------------------------
+struct C2Min {                               // 0 icm 16 ; 1 isse 19 0
+  static constexpr uint32_t id = 1, n = 2, depth = 1, final_lane = 1, nmix = 0;
+  static constexpr uint64_t icm = 0x1, isse = 0x2;
+  static constexpr int match_lane = -1;
+  static constexpr uint32_t mix_lane[2] = {0, 0}, mix_j0[2] = {0, 0}, mix_m[2] = {0, 0};
+  static constexpr bool has_tail = false;
+};
+struct C2Mid {                               // 0 icm ; 1-5 isse ; 6 match ; 7 mix 16 0 7 24 255
+  static constexpr uint32_t id = 2, n = 8, depth = 5, final_lane = 7, nmix = 1;
+  static constexpr uint64_t icm = 0x01, isse = 0x3e;
+  static constexpr int match_lane = 6;
+  static constexpr uint32_t mix_lane[2] = {7, 0}, mix_j0[2] = {0, 0}, mix_m[2] = {7, 0};
+  static constexpr bool has_tail = false;
+};
+
+typedef uint32_t v2u_ __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u_ __attribute__((ext_vector_type(4)));
+constexpr int kHWords = 256, kMBytes = 4096, kCodeBytes = 2048, kPHWords = 256, kPMBytes = 1024;
+constexpr int kEntUnits = 15;                 // ICM / ISSE entry tables of 256 x 8 bytes
+
+struct alignas(16) C2Lds {
+  int16_t stretch[32768];                     // at LDS offset 0 of this struct: see lds_stretch()
+  uint16_t squash[4096];
+  int32_t dt[1024];
+  int32_t dt2k[256];
+  uint8_t ns[1024];
+  v2u_ ent[kEntUnits][256];                  // {A, B}: ISSE {w0, w1} (Predictor.cs:148-152), ICM {cm, stretch(cm >> 8)}
+  v4u_ slot[64];                             // per-lane hash row of the current nibble
+  v4u_ zrow;                                 // all-zero row read by lanes without a hash table
+  v2u_ lent[64];                             // per-lane entry cell of those lanes
+  uint32_t lsink[64];                         // per-lane sink for their bit-history writes
+  uint32_t hreg[kHWords];
+  uint8_t mreg[kMBytes];
+  uint32_t r[256], pr[256];
+  uint8_t code[kCodeBytes];
+  uint32_t phreg[kPHWords];
+  uint8_t pmreg[kPMBytes];
+  Vm hz, pz;
+  Sink sink;
+};
+static_assert(sizeof(C2Lds) <= 163840, "LDS budget");
+
+typedef __attribute__((address_space(3))) uint8_t *lds_u8_p;
+typedef __attribute__((address_space(3))) uint16_t *lds_u16_p;
+typedef __attribute__((address_space(3))) int16_t *lds_i16_p;
+typedef __attribute__((address_space(3))) uint32_t *lds_u32_p;
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));   // native vectors: usable through address_space(3) pointers
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v2u *lds_u2_p;
+typedef __attribute__((address_space(3))) v4u *lds_u4_p;
+__device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(uintptr_t)p; }
+
+__device__ __forceinline__ int med3i(int x, int lo, int hi) { return x < lo ? lo : x > hi ? hi : x; }
+__device__ __forceinline__ int shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }   // row_shr:1, 0 shifted in
+__device__ __forceinline__ int dpp_shr(int v, int n) {
+  switch (n) {
+    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    case 2: return __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    case 4: return __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    default: return __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  }
+}
+
+constexpr uint32_t kOob = 0x80000000u;        // buffer offset beyond every arena slot of this family (< 2 GiB): dropped
+
+template <class SP>
+__device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) {
+  const uint32_t lane = threadIdx.x;
+  constexpr uint64_t kII = SP::icm | SP::isse;
+  const bool l_isse = (SP::isse >> lane) & 1, l_ii = (kII >> lane) & 1;
+  const bool l_match = SP::match_lane >= 0 && lane == (uint32_t)SP::match_lane;
+
+  {  // model-independent tables -> LDS (ZhTables: squash, stretch, dt, dt2k, ns)
+    const ZhTables *T = L.tables;
+    for (uint32_t i = lane; i < 32768 / 8; i += 64) reinterpret_cast<uint4 *>(S.stretch)[i] = reinterpret_cast<const uint4 *>(T->stretch)[i];
+    for (uint32_t i = lane; i < 4096 / 8; i += 64) reinterpret_cast<uint4 *>(S.squash)[i] = reinterpret_cast<const uint4 *>(T->squash)[i];
+    for (uint32_t i = lane; i < 1024 / 4; i += 64) reinterpret_cast<uint4 *>(S.dt)[i] = reinterpret_cast<const uint4 *>(T->dt)[i];
+    for (uint32_t i = lane; i < 256 / 4; i += 64) reinterpret_cast<uint4 *>(S.dt2k)[i] = reinterpret_cast<const uint4 *>(T->dt2k)[i];
+    for (uint32_t i = lane; i < 1024 / 16; i += 64) reinterpret_cast<uint4 *>(S.ns)[i] = reinterpret_cast<const uint4 *>(T->ns)[i];
+    if (lane == 0) S.zrow = v4u_{0, 0, 0, 0};
+  }
+  __syncthreads();
+
+  uint8_t *slot_mem = L.arena + (uint64_t)blockIdx.x * L.arena_stride;
+  const lds_i16_p lds_stretch = (lds_i16_p)lds_off(S.stretch);
+  const lds_u16_p lds_squash = (lds_u16_p)lds_off(S.squash);
+  const uint32_t ns_off = lds_off(S.ns);
+
+  for (;;) {
+    uint32_t bi = 0;
+    if (lane == 0) bi = atomicAdd(L.queue, 1u);
+    bi = uni((uint32_t)__shfl((int)bi, 0));
+    if (bi >= L.n_blocks) break;                       // every wave reaches this exit
+
+    const ZhBlockDesc *bdp = &L.blocks[bi];
+    const uint32_t model_i = uni(bdp->model);
+    const uint32_t first_seg = uni(bdp->first_seg), n_seg = uni(bdp->n_seg);
+    const uint64_t b_out_off = uni64(bdp->out_off), b_out_cap = uni64(bdp->out_cap);
+    const ZhModel *M = &L.models[model_i];
+    const uint32_t hh = uni(M->hh), hmb = uni(M->hm);
+    const uint32_t arena_bytes = uni((uint32_t)M->arena_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slot_mem, 0, (int)arena_bytes, 0x00020000);
+
+    // ---- Predictor.init (Predictor.cs:82-171): the arena tables this kernel keeps in HBM
+    for (uint32_t i = 0; i < SP::n; ++i) {
+      const ZhComp &cp = M->comp[i];
+      const uint32_t type = uni(cp.type);
+      uint8_t *cm = slot_mem + uni64(cp.cm_off), *ht = slot_mem + uni64(cp.ht_off);
+      const uint64_t cmb = uni64(cp.cm_bytes), htb = uni64(cp.ht_bytes);
+      uint4 pat = make_uint4(0, 0, 0, 0);
+      bool fill_cm = false;
+      if (type == ZH_MATCH) fill_cm = true;
+      else if (type == ZH_MIX2) { pat = make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u); fill_cm = true; }
+      else if (type == ZH_MIX) { const uint32_t w = 65536u / uni(cp.arg[2]); pat = make_uint4(w, w, w, w); fill_cm = true; }
+      if (fill_cm) { uint4 *q = reinterpret_cast<uint4 *>(cm); for (uint64_t k = lane; k < cmb / 16; k += 64) q[k] = pat; }
+      if (type == ZH_SSE) {                              // squash((j&31)*64-992)<<17 | start, period 32 entries
+        const uint32_t start = uni(cp.arg[2]);
+        uint4 *q = reinterpret_cast<uint4 *>(cm);
+        for (uint64_t k = lane; k < cmb / 16; k += 64) {
+          const uint32_t j = (uint32_t)(k * 4) & 31;
+          uint4 v;
+          v.x = (uint32_t)S.squash[(j + 0) * 64 - 992 + 2048] << 17 | start;
+          v.y = (uint32_t)S.squash[(j + 1) * 64 - 992 + 2048] << 17 | start;
+          v.z = (uint32_t)S.squash[(j + 2) * 64 - 992 + 2048] << 17 | start;
+          v.w = (uint32_t)S.squash[(j + 3) * 64 - 992 + 2048] << 17 | start;
+          q[k] = v;
+        }
+      }
+      if (type == ZH_ICM || type == ZH_ISSE || type == ZH_MATCH) {
+        uint4 *q = reinterpret_cast<uint4 *>(ht);
+        for (uint64_t k = lane; k < htb / 16; k += 64) q[k] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    {  // VM memories: arena tail zeroed; LDS copies zeroed
+      const uint64_t h_off = uni64(M->h_off), tail = uni64(M->arena_bytes) - h_off;
+      uint4 *z = reinterpret_cast<uint4 *>(slot_mem + h_off);
+      for (uint64_t i = lane; i < tail / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
+      for (uint32_t i = lane; i < 256; i += 64) { S.r[i] = 0; S.pr[i] = 0; S.hreg[i] = 0; }
+      for (uint32_t i = lane; i < kMBytes / 4; i += 64) reinterpret_cast<uint32_t *>(S.mreg)[i] = 0;
+      for (uint32_t i = lane; i < kPHWords; i += 64) S.phreg[i] = 0;
+      for (uint32_t i = lane; i < kPMBytes / 4; i += 64) reinterpret_cast<uint32_t *>(S.pmreg)[i] = 0;
+    }
+    // ---- ICM / ISSE entry tables in LDS.  Unit u of S.ent belongs to the u-th ICM/ISSE lane.
+    const uint32_t unit = (uint32_t)__builtin_popcountll(kII & ((1ull << lane) - 1));
+    {
+      // the 256 initial entries are the same for every ICM and for every ISSE: compute them once with 64 lanes
+      for (uint32_t j = lane; j < 256; j += 64) {
+        const uint32_t n0 = S.ns[j * 4 + 2], n1 = S.ns[j * 4 + 3];
+        const uint32_t ci = ((n1 * 2 + 1) << 22) / (n0 + n1 + 1);                  // StateTable.cminit
+        const int stv = S.stretch[ci >> 8];
+        const v2u e_icm = {ci, (uint32_t)stv};
+        const v2u e_isse = {1u << 15, (uint32_t)clamp512k(stv * 1024)};
+        uint32_t u = 0;
+        for (uint32_t i = 0; i < SP::n; ++i) {
+          if (!((kII >> i) & 1)) continue;
+          S.ent[u][j] = ((SP::icm >> i) & 1) ? e_icm : e_isse;
+          ++u;
+        }
+      }
+      S.slot[lane] = v4u{0, 0, 0, 0};
+      S.lent[lane] = v2u{0, 0};
+      S.lsink[lane] = 0;
+    }
+    __syncthreads();
+
+    // ---- per-lane constants
+    const ZhComp *mycp = &M->comp[lane < SP::n ? lane : 0];
+    const uint32_t hto = l_ii || l_match ? (uint32_t)mycp->ht_off : 0u, ht_mask = mycp->ht_mask;
+    const uint32_t cmo = (uint32_t)mycp->cm_off, cm_mask = mycp->cm_mask;
+    const uint32_t sizebits2 = (uint32_t)mycp->arg[0] + 2;
+    const uint32_t tab = l_ii ? lds_off(&S.ent[unit][0]) : lds_off(&S.lent[lane]);     // entry table of this lane
+    const uint32_t rrow = l_ii ? lds_off(&S.slot[lane]) : lds_off(&S.zrow);            // row it reads bit histories from
+    const uint32_t wrow = l_ii ? lds_off(&S.slot[lane]) : lds_off(&S.lsink[lane]);     // ... and writes them to (+ node index)
+    const uint32_t wrow_mask = l_ii ? 15u : 0u;
+    const int isse_m = l_isse ? -1 : 0;
+    const uint32_t cshift = l_isse ? 6u : 16u;
+    int pself = 0;                                       // prediction of a lane that is neither ICM nor ISSE (MATCH, CONST)
+    if (lane < SP::n && mycp->type == ZH_CONS) pself = ((int)mycp->arg[0] - 128) * 4;
+    if (l_match && lane == (uint32_t)SP::match_lane) (slot_mem + hto)[0] = 1;           // Predictor.cs:121 ht(0)=1 ... overwritten like the reference
+
+    // mixers kept in HBM: lane j0+k owns weight k of the current row
+    uint32_t vo_mix[2] = {kOob, kOob};                   // lane offset inside a row, out of range for lanes that do not feed it
+    uint32_t mx_base[2] = {0, 0}, mx_m4[2] = {0, 0}, mx_size1[2] = {0, 0}, mx_cmask[2] = {0, 0};
+    int mx_rate[2] = {0, 0};
+#pragma unroll
+    for (uint32_t q = 0; q < SP::nmix; ++q) {
+      const ZhComp &mc = M->comp[SP::mix_lane[q]];
+      mx_base[q] = uni((uint32_t)mc.cm_off);
+      mx_m4[q] = SP::mix_m[q] * 4u;
+      mx_size1[q] = uni(mc.cm_mask);                      // contexts - 1
+      mx_cmask[q] = uni((uint32_t)mc.arg[4]);
+      mx_rate[q] = (int)uni((uint32_t)mc.arg[3]);
+      if (lane >= SP::mix_j0[q] && lane < SP::mix_j0[q] + SP::mix_m[q]) vo_mix[q] = (lane - SP::mix_j0[q]) * 4u;
+    }
+
+    // HCOMP machine (ZPAQL.cs:1010-1026): H and M in LDS
+    Vm &hz = S.hz;
+    hz.a = hz.b = hz.c = hz.d = hz.f = 0;
+    hz.len = uni(M->hcomp_len);
+    {
+      const uint8_t *gcode = L.code + uni(M->code_off);
+      const uint32_t win = hz.len + 2 * ZH_CODE_PAD;
+      if (win <= (uint32_t)kCodeBytes) {
+        for (uint32_t i = lane; i < win; i += 64) S.code[i] = gcode[i];
+        hz.prog = S.code + ZH_CODE_PAD;
+      } else hz.prog = gcode + ZH_CODE_PAD;
+    }
+    hz.hmask = (uint32_t)((1ull << hh) - 1); hz.mmask = (uint32_t)((1ull << hmb) - 1);
+    hz.h = S.hreg; hz.m = S.mreg; hz.r = S.r;             // the three models have hh <= 5, hm <= 9
+    const uint32_t hmask = hz.hmask;
+    const uint32_t hnative = (uni(M->kind) >> 8) & 255;
+    uint32_t ha = 0, hb = 0, hc = 0, hd = 0, hf = 0;
+    const lds_u8_p lds_m = (lds_u8_p)lds_off(S.mreg);
+    const lds_u32_p lds_h = (lds_u32_p)lds_off(S.hreg);
+
+    int pp_state = 0, pp_hsize = 0;                    // PostProcessor (PostProcessor.cs:12-16)
+    uint32_t pp_len = 0;
+    Vm &pz = S.pz;
+    pz.a = pz.b = pz.c = pz.d = pz.f = 0;
+    pz.prog = nullptr; pz.len = 0;
+    const uint32_t phb = uni(M->ph), pmb = uni(M->pm);
+    pz.mmask = (uint32_t)((1ull << pmb) - 1); pz.hmask = (uint32_t)((1ull << phb) - 1);
+    pz.m = pmb < 31 && (1u << pmb) <= (uint32_t)kPMBytes ? S.pmreg : slot_mem + uni64(M->pm_off);
+    pz.h = phb < 31 && (1u << phb) <= (uint32_t)kPHWords ? S.phreg : reinterpret_cast<uint32_t *>(slot_mem + uni64(M->ph_off));
+    pz.r = S.pr;
+    const bool p_lds = pz.m == S.pmreg && pz.h == S.phreg;
+    uint32_t pnative = 0;
+    uint32_t pa = 0, pb = 0, pc_ = 0, pd = 0, pf = 0;
+    uint8_t *pzbuf = slot_mem + uni64(M->pz_off) + ZH_CODE_PAD;
+
+    Dec d;
+    d.low = 1; d.high = 0xFFFFFFFFu; d.curr = 0;
+    OutBuf ob;
+    ob.base = L.out + b_out_off; ob.cap = b_out_cap; ob.len = 0; ob.stored = 0; ob.word = 0; ob.park = 0;
+    out_room(ob);
+    Sink &sink = S.sink;
+    sink.out = ob.base; sink.cap = ob.cap; sink.len = 0;
+    __syncthreads();
+    InBuf in;
+    in.stream = L.in; in.total = L.in_total; in.cbase = 0; in.k = 0; in.avail = 0; in.cur = 0;
+
+    // ---- state carried from bit to bit
+    uint32_t hv = 0;                                    // h[lane] (Predictor.cs:469)
+    uint32_t rowoff = 0;                                // arena offset of the hash row held in S.slot[lane]
+    bool rowvalid = false;
+    uint32_t ea = tab;                                  // LDS address of the entry the current bit uses
+    uint32_t st = 0;                                    // its bit-history state
+    uint32_t eA = 0, eB = 0;                            // its value
+    int mw[2] = {0, 0};                                 // weight of this lane in the current row of each HBM mixer
+    uint32_t mrow[2] = {0, 0};                          // arena offset of that row (scalar)
+    // MATCH (Predictor.cs:273-287, 382-411): the lane's Component fields
+    uint32_t m_len = 0, m_ptr = 0, m_limit = 0, m_byte = 0;
+    int pm0 = 0, pm1 = 0;                               // stretch of -+dt2k[len] for this byte; 0 once the match has failed
+
+    // Hash rows of the nibble that starts now (c8 == 1 or 16 <= c8 < 32), Predictor.find (Predictor.cs:550-567).
+    // issue: the three candidate rows are requested; `old` is the row this lane holds (just evicted, maybe still in
+    // flight to HBM): a candidate at the same place is taken from it, so the requests need not wait for the write-back.
+    struct Probe { v4u r0, r1, r2; uint32_t h0, chk; };
+    auto rows_issue = [&](uint32_t c8, Probe &pr) __attribute__((always_inline)) {
+      const uint32_t cxt = hv + 16u * c8;
+      pr.chk = (cxt >> sizebits2) & 255;
+      pr.h0 = (cxt * 16u) & (ht_mask - 15u);
+      const uint32_t vo = l_ii ? hto + pr.h0 : kOob;
+      pr.r0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
+      pr.r1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo ^ 16u, 0, 0);
+      pr.r2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo ^ 32u, 0, 0);
+    };
+    auto rows_finish = [&](Probe &pr, const v4u &old, uint32_t old_off, bool old_valid) __attribute__((always_inline)) {
+      const uint32_t h0 = pr.h0, h1 = h0 ^ 16u, h2 = h0 ^ 32u;
+      v4u r0 = pr.r0, r1 = pr.r1, r2 = pr.r2;
+      if (old_valid && old_off == h0) r0 = old;
+      if (old_valid && old_off == h1) r1 = old;
+      if (old_valid && old_off == h2) r2 = old;
+      const uint32_t chk = pr.chk;
+      const bool m0 = (r0.x & 255) == chk, m1 = (r1.x & 255) == chk, m2 = (r2.x & 255) == chk;
+      const uint32_t p0 = (r0.x >> 8) & 255, p1 = (r1.x >> 8) & 255, p2 = (r2.x >> 8) & 255;
+      const uint32_t victim = (p0 <= p1 && p0 <= p2) ? h0 : p1 < p2 ? h1 : h2;
+      const uint32_t sel = m0 ? h0 : m1 ? h1 : m2 ? h2 : victim;
+      const v4u fresh = {chk, 0, 0, 0};
+      const v4u row = m0 ? r0 : m1 ? r1 : m2 ? r2 : fresh;
+      *(lds_u4_p)lds_off(&S.slot[lane]) = row;           // lanes without a hash table never read their slot
+      rowoff = sel; rowvalid = true;
+    };
+    // write the row of the finished nibble back (fire and forget) and hand its content to the caller
+    auto row_evict = [&](v4u &old, uint32_t &old_off, bool &old_valid) __attribute__((always_inline)) {
+      old = *(lds_u4_p)lds_off(&S.slot[lane]);
+      old_off = rowoff; old_valid = rowvalid && l_ii;
+      __builtin_amdgcn_raw_buffer_store_b128(old, rsrc, old_valid ? hto + rowoff : kOob, 0, 0);
+    };
+    // first bit of a nibble: node 1 of the row now in S.slot, read directly
+    auto l0_direct = [&]() __attribute__((always_inline)) {
+      st = *(lds_u8_p)(rrow + 1);
+      ea = tab + st * 8u;
+      const v2u e = *(lds_u2_p)ea;
+      eA = e.x; eB = e.y;
+    };
+    auto mix_row = [&](uint32_t q, uint32_t hq, uint32_t c8) __attribute__((always_inline)) -> uint32_t {
+      return uni(mx_base[q] + ((uni(hq) + (c8 & mx_cmask[q])) & mx_size1[q]) * mx_m4[q]);   // pinned to the scalar unit
+    };
+    uint32_t mx_h[2] = {0, 0};                           // h[] of the mixer components (scalar)
+
+    int failed = 0;
+    for (uint32_t s = 0; s < n_seg; ++s) {
+      const uint32_t si = first_seg + s;
+      const uint64_t produced0 = pp_state == 5 ? uni64(sink.len) : ob.len;
+      int status = 0;
+      if (failed) {
+        if (lane == 0) {
+          ZhSegResult res;
+          res.status = ZH_E_SKIPPED; res.pp_state = (uint32_t)pp_state; res.out_off = b_out_off + produced0; res.out_len = 0;
+          res.in_used = 0;
+          L.results[si] = res;
+        }
+        continue;
+      }
+      const uint64_t seg_off = uni64(L.segs[si].in_off);
+      in_seek(in, seg_off, lane);
+      if (s == 0) {                                      // first nibble of the block (h[] = 0)
+        Probe pr;
+        rows_issue(1u, pr);
+        rows_finish(pr, v4u{0, 0, 0, 0}, 0u, false);
+#pragma unroll
+        for (uint32_t q = 0; q < SP::nmix; ++q) {
+          mrow[q] = mix_row(q, 0u, 1u);
+          mw[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow[q], 0);
+        }
+      }
+
+      for (;;) {                                       // one decoded byte per iteration
+        // ---- Decoder.decompress prologue (Decoder.cs:36-45)
+        if (UNLIKELY(d.curr == 0)) {
+          uint32_t cu = 0;
+          for (int i = 0; i < 4; ++i) cu = cu << 8 | (uint32_t)in_get(in, lane);
+          d.curr = uni(cu);
+        }
+        uint32_t bad = 0, rn, j = 0, err = 0;
+        d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr);
+        ZH_DEC_STEP(d, 0u, j, bad, rn);                // EOS flag: p = 0
+        if (UNLIKELY(bad)) { status = ZH_E_CORRUPT; break; }
+        if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane)) { status = ZH_E_EOF; break; } }
+        int c;
+        if (UNLIKELY(j)) {
+          if (d.curr != 0) { status = ZH_E_EOS; break; }
+          c = -1;
+        } else {
+          uint32_t c8 = 1;
+          // ======== one bit.  NODE = position in the nibble (0..3); the node index is hm (1, 2-3, 4-7, 8-15).
+          uint32_t hm = 1;
+          uint32_t pairS = 0;                            // bit histories of nodes 2hm, 2hm+1
+          l0_direct();
+#pragma unroll
+          for (int bit = 0; bit < 8; ++bit) {
+            const bool pre_ii = (bit & 3) != 3;          // the next bit stays in this nibble: fetch both of its nodes
+            const bool pre_mx = bit != 7;                // the next bit stays in this byte: fetch both of its mixer rows
+            hm = uni(hm); c8 = uni(c8);
+            // ---- (a) requests for the NEXT bit, both ways
+            uint32_t ea0 = 0, ea1 = 0;
+            v2u e0 = {0, 0}, e1 = e0;
+            if (pre_ii) pairS = *(lds_u16_p)(rrow + 2u * hm);
+            int mwc0[2] = {0, 0}, mwc1[2] = {0, 0};
+            uint32_t mrow0[2] = {0, 0}, mrow1[2] = {0, 0};
+            if (pre_mx) {
+#pragma unroll
+              for (uint32_t q = 0; q < SP::nmix; ++q) {
+                mrow0[q] = mix_row(q, mx_h[q], c8 * 2u);
+                mrow1[q] = mix_row(q, mx_h[q], c8 * 2u + 1u);
+                mwc0[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow0[q], 0);
+                mwc1[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow1[q], 0);
+              }
+            }
+            // ---- (b) predict: operands of the systolic ISSE step
+            int xs = pself;
+            if (SP::match_lane >= 0) {                   // MATCH predicts the next bit of the byte it points at
+              const uint32_t cbit = (m_byte >> (7 - bit)) & 1;
+              xs = cbit ? pm1 : pm0;                     // (only the MATCH lane holds non-zero pm0 / pm1)
+            }
+            const int x = l_ii ? (int)eB : xs;
+            const int cw0 = (int)eA & isse_m;
+            const int cw1m = (int)((uint32_t)x << cshift);
+            int p = x;
+            if (pre_ii) {                                // second half of (a): the two entries (their addresses came back)
+              ea0 = tab + (pairS & 255u) * 8u;
+              ea1 = tab + (pairS >> 8) * 8u;
+              e0 = *(lds_u2_p)ea0;
+              e1 = *(lds_u2_p)ea1;
+            }
+#pragma unroll
+            for (uint32_t t = 0; t < SP::depth; ++t) p = med3i((__mul24(shr1(p), cw0) + cw1m) >> 16, -2048, 2047);
+            // ---- (c) mixers
+            if (SP::nmix >= 1) {
+              int term = __mul24(mw[0] >> 8, p);         // lanes that do not feed the mixer hold weight 0
+              term += dpp_shr(term, 1); term += dpp_shr(term, 2); term += dpp_shr(term, 4);
+              if (SP::mix_m[0] > 8) term += dpp_shr(term, 8);
+              const int pmx = med3i(term >> 8, -2048, 2047);
+              if (lane == SP::mix_lane[0]) p = pmx;
+            }
+            // ---- (d) decode
+            const int sqp = (int)*(lds_u16_p)((uint32_t)(uintptr_t)lds_squash + (uint32_t)(p + 2048) * 2u);
+            const uint32_t prb = rdlane((uint32_t)sqp, SP::final_lane);
+            const uint32_t ps = (prb * 2 + 1) << 16;
+            uint32_t jb = j;
+            ZH_DEC_STEP(d, ps, jb, bad, rn);
+            j = jb;
+            if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane) && !err) err = bad ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF; }
+            const uint32_t y = uni(j & 1);
+            const int ey = y ? 32767 : 0;
+            // ---- (e) update (Predictor.cs:363-461)
+            const int e = ey - sqp;
+            // bit history of this node: next(state, y) -> row byte
+            const uint32_t nsb = *(lds_u8_p)(ns_off + st * 4u + y);
+            // ICM (Predictor.cs:375-381) and ISSE (:440-449), every lane computes both
+            const uint32_t ncm = eA + (uint32_t)((int)(ey - (int)(eA >> 8)) >> 2);
+            const int npst = *(lds_i16_p)((uint32_t)(uintptr_t)lds_stretch + ((ncm >> 7) & 0x1fffeu));
+            const int pj = shr1(p);
+            const int nw0 = med3i((int)eA + ((__mul24(e, pj) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
+            const int nw1 = med3i((int)eB + ((e + 16) >> 5), -(1 << 19), (1 << 19) - 1);
+            if (SP::nmix >= 1) {                         // MIX (Predictor.cs:427-439): error from the mixer lane
+              const int emix = __mul24(e, mx_rate[0]) >> 4;
+              const int eq = (int)rdlane((uint32_t)emix, SP::mix_lane[0]);
+              const int nmw = med3i(mw[0] + ((__mul24(eq, p) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
+              __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw, rsrc, vo_mix[0], mrow[0], 0);
+            }
+            if (SP::match_lane >= 0) {                   // MATCH (Predictor.cs:383-384): a miss ends the match
+              const uint32_t cbit = (m_byte >> (7 - bit)) & 1;
+              const bool miss = cbit != y;
+              m_len = miss ? 0u : m_len; pm0 = miss ? 0 : pm0; pm1 = miss ? 0 : pm1;
+            }
+            const uint32_t nA = l_isse ? (uint32_t)nw0 : ncm, nB = l_isse ? (uint32_t)nw1 : (uint32_t)npst;
+            *(lds_u2_p)ea = v2u{nA, nB};
+            *(lds_u8_p)(wrow + (hm & wrow_mask)) = (uint8_t)nsb;
+            // ---- (f) bookkeeping (Predictor.cs:463-474) and hand-over to the next bit
+            c8 = c8 * 2u + y;
+            if (pre_mx) {
+#pragma unroll
+              for (uint32_t q = 0; q < SP::nmix; ++q) { mw[q] = y ? mwc1[q] : mwc0[q]; mrow[q] = y ? mrow1[q] : mrow0[q]; }
+            }
+            if (pre_ii) {
+              hm = hm * 2u + y;
+              const uint32_t nea = y ? ea1 : ea0;
+              const bool same = nea == ea;               // bit k trained the entry bit k+1 predicts from
+              st = y ? pairS >> 8 : pairS & 255u;
+              eA = same ? nA : (y ? e1.x : e0.x);
+              eB = same ? nB : (y ? e1.y : e0.y);
+              ea = nea;
+            } else if (bit == 3) {
+              // ---- second nibble (Predictor.cs:267-270: c8 & 0xf0 == 16): new rows
+              v4u old; uint32_t old_off; bool old_valid;
+              row_evict(old, old_off, old_valid);
+              Probe pr;
+              rows_issue(c8, pr);
+              rows_finish(pr, old, old_off, old_valid);
+              hm = 1;
+              l0_direct();
+            }
+          }
+          if (UNLIKELY(err | bad)) { status = err ? -(int)err : ZH_E_CORRUPT; break; }
+          c = (int)(c8 - 256);
+
+          // ---- byte boundary: MATCH (Predictor.cs:391-410), HCOMP, h[], rows of the next byte
+          {
+            uint32_t cmv = 0;
+            if (l_match) {                               // still with the h[i] of the byte just coded (update0 runs before z.run)
+              (slot_mem + hto)[m_limit & ht_mask] = (uint8_t)c;
+              m_limit = (m_limit + 1) & ht_mask;
+              uint32_t *cm = reinterpret_cast<uint32_t *>(slot_mem + cmo);
+              cmv = cm[hv & cm_mask];
+              cm[hv & cm_mask] = m_limit;
+            }
+            int rc;
+            switch (hnative) {
+              case ZH_NATIVE_HCOMP_MIN: rc = zh_native_hcomp_min(ha, hb, hc, hd, hf, (uint32_t)c, lds_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
+              case ZH_NATIVE_HCOMP_MID: rc = zh_native_hcomp_mid(ha, hb, hc, hd, hf, (uint32_t)c, lds_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
+              case ZH_NATIVE_HCOMP_MAX: rc = zh_native_hcomp_max(ha, hb, hc, hd, hf, (uint32_t)c, lds_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
+              default: rc = vm_run(hz, (uint32_t)c, nullptr, L.budget); break;
+            }
+            rc = (int)uni((uint32_t)rc);
+            if (rc) { status = rc; break; }
+            hv = lds_h[lane & hmask];
+            v4u old; uint32_t old_off; bool old_valid;
+            row_evict(old, old_off, old_valid);
+            Probe pr;
+            rows_issue(1u, pr);
+#pragma unroll
+            for (uint32_t q = 0; q < SP::nmix; ++q) {
+              mx_h[q] = rdlane(hv, SP::mix_lane[q]);
+              mrow[q] = mix_row(q, mx_h[q], 1u);
+              mw[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow[q], 0);
+            }
+            if (SP::match_lane >= 0) {
+              uint32_t need = 0;
+              if (l_match) {
+                if (m_len == 0) {
+                  m_ptr = m_limit - cmv;
+                  need = (m_ptr & ht_mask) != 0;
+                } else m_len += m_len < 255;
+              }
+              if (__ballot(need != 0)) {                 // verify the candidate with the whole wave (Predictor.cs:403-405)
+                const uint32_t ml = (uint32_t)SP::match_lane;
+                const uint32_t lim = rdlane(m_limit, ml), off = rdlane(m_ptr, ml), msk = rdlane(ht_mask, ml);
+                const uint8_t *hp = slot_mem + rdlane(hto, ml);
+                uint32_t len = 0;
+                for (uint32_t base = 0; base < 256; base += 64) {
+                  const uint32_t t = base + lane;
+                  const bool eq = t < 255 && hp[(lim - t - 1) & msk] == hp[(lim - t - off - 1) & msk];
+                  const uint64_t mism = __ballot(!eq);
+                  if (mism) { len += (uint32_t)__builtin_ctzll(mism); break; }
+                  len += 64;
+                }
+                if (l_match) m_len = len > 255 ? 255 : len;
+              }
+              if (l_match) m_byte = (slot_mem + hto)[(m_limit - m_ptr) & ht_mask];
+              const int dk = S.dt2k[l_match ? m_len : 0];
+              pm0 = S.stretch[dk & 32767];
+              pm1 = S.stretch[(-dk) & 32767];
+              if (!l_match || m_len == 0) { pm0 = 0; pm1 = 0; }
+            }
+            rows_finish(pr, old, old_off, old_valid);
+          }
+        }
+
+        // ---- PostProcessor.write(c) (PostProcessor.cs:37-86)
+        c = (int)uni((uint32_t)c);
+        if (LIKELY(pp_state == 1)) {
+          if (LIKELY(c >= 0)) out_put(ob, (uint32_t)c, lane);
+        } else if (pp_state == 5) {
+          int rc;
+          if (pnative == ZH_NATIVE_PCOMP_E8E9)
+            rc = zh_native_pcomp_e8e9(pa, pb, pc_, pd, pf, (uint32_t)c, (lds_u8_p)lds_off(S.pmreg), pz.mmask, (lds_u32_p)lds_off(S.phreg), pz.hmask, S.pr, &sink, L.budget);
+          else rc = vm_run(pz, (uint32_t)c, &sink, L.budget);
+          rc = (int)uni((uint32_t)rc);
+          if (rc) { status = rc; break; }
+        } else if (pp_state == 0) {
+          if (c < 0) { status = ZH_E_PP_EOS; break; }
+          pp_state = c + 1;
+          if (pp_state > 2) { status = ZH_E_PP_TYPE; break; }
+        } else if (pp_state == 2) {
+          if (c < 0) { status = ZH_E_PP_EOS; break; }
+          pp_hsize = c; pp_state = 3;
+        } else if (pp_state == 3) {
+          if (c < 0) { status = ZH_E_PP_EOS; break; }
+          pp_hsize += c * 256;
+          if (pp_hsize < 1) { status = ZH_E_PP_EMPTY; break; }
+          pp_len = 0; pp_state = 4;
+        } else {                                        // state 4: PCOMP bytes
+          if (c < 0) { status = ZH_E_PP_EOS; break; }
+          pzbuf[pp_len] = (uint8_t)c;
+          if ((int)++pp_len == pp_hsize) {
+            __syncthreads();
+            pz.prog = pzbuf; pz.len = pp_len;
+            pz.a = pz.b = pz.c = pz.d = pz.f = 0;
+            pnative = p_lds ? uni(zh_native_lookup(pzbuf, pp_len)) : 0;
+            pp_state = 5;
+          }
+        }
+        if (c < 0) break;
+      }
+
+      if (pp_state != 5) out_flush(ob, lane);
+      const uint64_t produced = pp_state == 5 ? uni64(sink.len) : ob.len;
+      if (!status && produced > b_out_cap) status = ZH_E_OUTPUT_FULL;
+      if (status && status != ZH_E_OUTPUT_FULL) failed = 1;
+      if (lane == 0) {
+        ZhSegResult res;
+        res.status = status; res.pp_state = (uint32_t)pp_state | (uint32_t)pp_hsize << 8;
+        res.out_off = b_out_off + produced0; res.out_len = produced - produced0;
+        res.in_used = in_pos(in) - seg_off;
+        L.results[si] = res;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+#define ZH_CHAIN2_KERNEL(name, spec)                                                   \
+  extern "C" __global__ __launch_bounds__(64) void name(ZhLaunch L) {                  \
+    __shared__ C2Lds S;                                                                \
+    decode_chain2_body<spec>(L, S);                                                    \
+  }
+ZH_CHAIN2_KERNEL(zh_decode_c2_min, C2Min)
+ZH_CHAIN2_KERNEL(zh_decode_c2_mid, C2Mid)
+
+// spec: 1 min, 2 mid (zh_chain_spec.h ids).  Returns hipErrorInvalidValue for a spec this file has no kernel for.
+extern "C" hipError_t zh_launch_chain2(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec) {
+  void (*k)(ZhLaunch) = spec == 1 ? zh_decode_c2_min : spec == 2 ? zh_decode_c2_mid : nullptr;
+  if (!k) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, stream, *L);
+  return hipGetLastError();
+}
+extern "C" int zh_chain2_has(uint32_t spec) { return spec == 1 || spec == 2; }
