@@ -57,6 +57,19 @@ struct C2Mid {                               // 0 icm ; 1-5 isse ; 6 match ; 7 m
 
 typedef uint32_t v2u_ __attribute__((ext_vector_type(2)));
 typedef uint32_t v4u_ __attribute__((ext_vector_type(4)));
+struct C2Max {                               // Compressor.cs:60-72: 0 const; 1 icm; 2-7 isse; 8 match; 9 icm; 10 isse; 11-14 icm;
+                                             // 15 mix 16 0 15 24 255; 16 mix 8 0 16 10 255; 17 mix2 0 15 16 24 0; 18 sse 8 17 32 255;
+                                             // 19 mix2 8 17 18 16 255; 20 sse 16 19 32 255; 21 mix2 0 19 20 16 0
+  static constexpr uint32_t id = 3, n = 22, depth = 6, final_lane = 21, nmix = 2;
+  static constexpr uint64_t icm = (1u << 1) | (1u << 9) | (1u << 11) | (1u << 12) | (1u << 13) | (1u << 14), isse = 0xfcu | (1u << 10);
+  static constexpr int match_lane = 8;
+  static constexpr uint32_t mix_lane[2] = {15, 16}, mix_j0[2] = {0, 0}, mix_m[2] = {15, 16};
+  static constexpr bool has_tail = true;
+  // tail constants (component arguments of the exact header this kernel is selected for)
+  static constexpr int rate17 = 24, rate19 = 16, rate21 = 16;
+  static constexpr uint32_t sse_limit = 255 * 4, sse_start = 32;
+};
+
 constexpr int kHWords = 256, kMBytes = 4096, kCodeBytes = 2048, kPHWords = 256, kPMBytes = 1024;
 constexpr int kEntUnits = 15;                 // ICM / ISSE entry tables of 256 x 8 bytes
 
@@ -71,6 +84,8 @@ struct alignas(16) C2Lds {
   v4u_ zrow;                                 // all-zero row read by lanes without a hash table
   v2u_ lent[64];                             // per-lane entry cell of those lanes
   uint32_t lsink[64];                         // per-lane sink for their bit-history writes
+  uint32_t sse18[256 * 32];                   // max: the table of `sse 8 17` (h = 0: row = c8), Predictor.cs:163-164
+  uint16_t a19[256];                          // max: the weights of `mix2 8 17 18`
   uint32_t hreg[kHWords];
   uint8_t mreg[kMBytes];
   uint32_t r[256], pr[256];
@@ -101,6 +116,13 @@ __device__ __forceinline__ int dpp_shr(int v, int n) {
     case 4: return __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
     default: return __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
   }
+}
+
+// park[LANE] = val (wave-uniform)
+template <int LANE>
+__device__ __forceinline__ int wrlane_c(int park, int val) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(park) : "s"((int)uni((uint32_t)val)), "n"(LANE));
+  return park;
 }
 
 constexpr uint32_t kOob = 0x80000000u;        // buffer offset beyond every arena slot of this family (< 2 GiB): dropped
@@ -198,6 +220,10 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
           S.ent[u][j] = ((SP::icm >> i) & 1) ? e_icm : e_isse;
           ++u;
         }
+      }
+      if (SP::has_tail) {
+        for (uint32_t k = lane; k < 256 * 32; k += 64) S.sse18[k] = (uint32_t)S.squash[(k & 31) * 64 - 992 + 2048] << 17 | C2Max::sse_start;
+        for (uint32_t k = lane; k < 256; k += 64) S.a19[k] = 32768;
       }
       S.slot[lane] = v4u{0, 0, 0, 0};
       S.lent[lane] = v2u{0, 0};
@@ -340,6 +366,24 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
       return uni(mx_base[q] + ((uni(hq) + (c8 & mx_cmask[q])) & mx_size1[q]) * mx_m4[q]);   // pinned to the scalar unit
     };
     uint32_t mx_h[2] = {0, 0};                           // h[] of the mixer components (scalar)
+    // ---- tail of the max model (components 17-21); the host routes a block here only with the built-in HCOMP, which
+    // leaves h[17] = h[18] = h[19] = h[21] = 0 and h[20] = byte << 9 (even), so the two rows a bit can lead to are one
+    // aligned row pair of each SSE table
+    int w17 = 32768, w21 = 32768;                        // mix2 with a single weight (sizebits 0): kept in registers
+    uint32_t w19 = 32768, a19i = 0;                      // mix2 19: current weight and its index in S.a19
+    uint32_t row18 = 0, row20 = 0;                       // per lane: entry (lane & 31) of row 2r + (lane >> 5) of the SSE tables
+    uint32_t t_h20 = 0;
+    const uint32_t sse20_base = SP::has_tail ? uni((uint32_t)M->comp[20].cm_off) : 0u, sse20_mask = SP::has_tail ? uni(M->comp[20].cm_mask) : 0u;
+    auto row18_load = [&](uint32_t c8x) __attribute__((always_inline)) -> uint32_t {     // rows (c8x & ~1), +1 of the LDS table
+      return *(lds_u32_p)(lds_off(S.sse18) + ((c8x & 254u) * 128u) + lane * 4u);
+    };
+    auto row20_load = [&](uint32_t c8x) __attribute__((always_inline)) -> uint32_t {
+      const uint32_t r = uni((((t_h20 + (c8x & ~1u)) * 32u) & sse20_mask) * 4u + sse20_base);
+      return __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4u, r, 0);
+    };
+    auto stretch_u = [&](uint32_t ix) __attribute__((always_inline)) -> int {             // stretch() of a wave-uniform argument
+      return (int)uni((uint32_t)(int)*(lds_i16_p)((uint32_t)(uintptr_t)lds_stretch + ix * 2u));
+    };
 
     int failed = 0;
     for (uint32_t s = 0; s < n_seg; ++s) {
@@ -366,6 +410,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
           mrow[q] = mix_row(q, 0u, 1u);
           mw[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow[q], 0);
         }
+        if (SP::has_tail) { row18 = row18_load(1u); row20 = row20_load(1u); a19i = 1u; w19 = uni((uint32_t)S.a19[1]); }
       }
 
       for (;;) {                                       // one decoded byte per iteration
@@ -410,11 +455,18 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
                 mwc1[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow1[q], 0);
               }
             }
+            uint32_t row18n = 0, row20n = 0, w19n0 = 0, w19n1 = 0;
+            if (SP::has_tail && pre_mx) {
+              row18n = row18_load(c8 * 2u);
+              row20n = row20_load(c8 * 2u);
+              const uint32_t wp = *(lds_u32_p)(lds_off(S.a19) + ((c8 * 2u) & 254u) * 2u);       // entries 2c8, 2c8+1
+              w19n0 = uni(wp) & 0xffffu; w19n1 = uni(wp) >> 16;
+            }
             // ---- (b) predict: operands of the systolic ISSE step
             int xs = pself;
             if (SP::match_lane >= 0) {                   // MATCH predicts the next bit of the byte it points at
               const uint32_t cbit = (m_byte >> (7 - bit)) & 1;
-              xs = cbit ? pm1 : pm0;                     // (only the MATCH lane holds non-zero pm0 / pm1)
+              xs = l_match ? (cbit ? pm1 : pm0) : pself;
             }
             const int x = l_ii ? (int)eB : xs;
             const int cw0 = (int)eA & isse_m;
@@ -429,7 +481,39 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
 #pragma unroll
             for (uint32_t t = 0; t < SP::depth; ++t) p = med3i((__mul24(shr1(p), cw0) + cw1m) >> 16, -2048, 2047);
             // ---- (c) mixers
-            if (SP::nmix >= 1) {
+            int p15 = 0, p16 = 0, p17 = 0, p18 = 0, p19 = 0, p20 = 0;       // max: the serial tail runs on the scalar unit
+            uint32_t sel18 = 0, sel20 = 0, ti18 = 0, ti20 = 0;
+            int dtv18 = 0, dtv20 = 0;
+            if constexpr (SP::id == 3) {
+              // MIX 15 over lanes 0-14, MIX 16 over lanes 0-15 (Predictor.cs:302-316): row sums land in lane 15
+              int t0 = __mul24(mw[0] >> 8, p);
+              t0 += dpp_shr(t0, 1); t0 += dpp_shr(t0, 2); t0 += dpp_shr(t0, 4); t0 += dpp_shr(t0, 8);
+              p15 = med3i((int)rdlane((uint32_t)t0, 15) >> 8, -2048, 2047);
+              p = wrlane_c<15>(p, p15);
+              int t1 = __mul24(mw[1] >> 8, p);
+              t1 += dpp_shr(t1, 1); t1 += dpp_shr(t1, 2); t1 += dpp_shr(t1, 4); t1 += dpp_shr(t1, 8);
+              p16 = med3i((int)rdlane((uint32_t)t1, 15) >> 8, -2048, 2047);
+              p17 = (w17 * p15 + (65536 - w17) * p16) >> 16;                 // MIX2 17 (Predictor.cs:291-301)
+              auto sse = [&](int pin, uint32_t rowv, int &pout, uint32_t &sel, uint32_t &ti, int &dtv) __attribute__((always_inline)) {
+                int pq = pin + 992;                                          // SSE (Predictor.cs:327-340)
+                pq = pq < 0 ? 0 : pq > 1983 ? 1983 : pq;
+                const uint32_t wt = (uint32_t)pq & 63u, iq = (uint32_t)pq >> 6;
+                const uint32_t lo = (c8 & 1u) * 32u + iq;                    // this bit's row is the (c8 & 1) half of the pair
+                const uint32_t e0 = rdlane(rowv, lo), e1 = rdlane(rowv, lo + 1u);
+                pout = stretch_u(((e0 >> 10) * (64u - wt) + (e1 >> 10) * wt) >> 13);
+                sel = (wt >> 5) ? e1 : e0;                                   // the entry train() will update
+                ti = iq + (wt >> 5);
+                dtv = (int)uni((uint32_t)S.dt[sel & 0x3ffu]);
+              };
+              sse(p17, row18, p18, sel18, ti18, dtv18);
+              p19 = (int)((int)w19 * p17 + (65536 - (int)w19) * p18) >> 16;  // MIX2 19
+              sse(p19, row20, p20, sel20, ti20, dtv20);
+              const int p21 = (w21 * p19 + (65536 - w21) * p20) >> 16;       // MIX2 21
+              p = wrlane_c<16>(p, p16);
+              p = wrlane_c<17>(p, p17);
+              p = wrlane_c<19>(p, p19);
+              p = wrlane_c<21>(p, p21);                   // lanes 18 and 20 (SSE) need no squash
+            } else if (SP::nmix >= 1) {
               int term = __mul24(mw[0] >> 8, p);         // lanes that do not feed the mixer hold weight 0
               term += dpp_shr(term, 1); term += dpp_shr(term, 2); term += dpp_shr(term, 4);
               if (SP::mix_m[0] > 8) term += dpp_shr(term, 8);
@@ -456,11 +540,34 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
             const int pj = shr1(p);
             const int nw0 = med3i((int)eA + ((__mul24(e, pj) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
             const int nw1 = med3i((int)eB + ((e + 16) >> 5), -(1 << 19), (1 << 19) - 1);
-            if (SP::nmix >= 1) {                         // MIX (Predictor.cs:427-439): error from the mixer lane
-              const int emix = __mul24(e, mx_rate[0]) >> 4;
-              const int eq = (int)rdlane((uint32_t)emix, SP::mix_lane[0]);
-              const int nmw = med3i(mw[0] + ((__mul24(eq, p) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
-              __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw, rsrc, vo_mix[0], mrow[0], 0);
+#pragma unroll
+            for (uint32_t q = 0; q < SP::nmix; ++q) {     // MIX (Predictor.cs:427-439): error from the mixer lane
+              const int eq = __mul24((int)rdlane((uint32_t)e, SP::mix_lane[q]), mx_rate[q]) >> 4;
+              const int nmw = med3i(mw[q] + ((__mul24(eq, p) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
+              __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw, rsrc, vo_mix[q], mrow[q], 0);
+            }
+            if constexpr (SP::id == 3) {
+              auto mix2_train = [&](int w, int rate, uint32_t ln, int pj_, int pk_) __attribute__((always_inline)) -> int {   // Predictor.cs:414-426
+                const int er = ((int)rdlane((uint32_t)e, ln) * rate) >> 5;
+                w += (er * (pj_ - pk_) + (1 << 12)) >> 13;
+                return w < 0 ? 0 : w > 65535 ? 65535 : w;
+              };
+              auto sse_train = [&](uint32_t pn, int dtv) __attribute__((always_inline)) -> uint32_t {                      // Predictor.train, :1031-1036 form
+                const uint32_t count = pn & 0x3ffu;
+                const int error = ey - (int)(pn >> 17);
+                return pn + (((uint32_t)error * (uint32_t)dtv) & 0xFFFFFC00u) + (count < C2Max::sse_limit);
+              };
+              w17 = mix2_train(w17, C2Max::rate17, 17, p15, p16);
+              const uint32_t n18 = sse_train(sel18, dtv18);
+              *(lds_u32_p)(lds_off(S.sse18) + ((c8 & 255u) * 32u + ti18) * 4u) = n18;
+              w19 = (uint32_t)mix2_train((int)w19, C2Max::rate19, 19, p17, p18);
+              *(lds_u16_p)(lds_off(S.a19) + a19i * 2u) = (uint16_t)w19;
+              const uint32_t n20 = sse_train(sel20, dtv20);
+              {
+                const uint32_t off = uni(((((t_h20 + c8) * 32u + ti20) & sse20_mask) * 4u) + sse20_base);
+                __builtin_amdgcn_raw_buffer_store_b32(n20, rsrc, lane == 0 ? 0u : kOob, off, 0);
+              }
+              w21 = mix2_train(w21, C2Max::rate21, 21, p19, p20);
             }
             if (SP::match_lane >= 0) {                   // MATCH (Predictor.cs:383-384): a miss ends the match
               const uint32_t cbit = (m_byte >> (7 - bit)) & 1;
@@ -475,6 +582,10 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
             if (pre_mx) {
 #pragma unroll
               for (uint32_t q = 0; q < SP::nmix; ++q) { mw[q] = y ? mwc1[q] : mwc0[q]; mrow[q] = y ? mrow1[q] : mrow0[q]; }
+            }
+            if (SP::has_tail && pre_mx) {
+              row18 = row18n; row20 = row20n;
+              w19 = y ? w19n1 : w19n0; a19i = c8 & 255u;
             }
             if (pre_ii) {
               hm = hm * 2u + y;
@@ -527,6 +638,11 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
               mx_h[q] = rdlane(hv, SP::mix_lane[q]);
               mrow[q] = mix_row(q, mx_h[q], 1u);
               mw[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow[q], 0);
+            }
+            if (SP::has_tail) {
+              t_h20 = rdlane(hv, 20);
+              row18 = row18_load(1u); row20 = row20_load(1u);
+              a19i = 1u; w19 = uni((uint32_t)S.a19[1]);
             }
             if (SP::match_lane >= 0) {
               uint32_t need = 0;
@@ -622,12 +738,13 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
   }
 ZH_CHAIN2_KERNEL(zh_decode_c2_min, C2Min)
 ZH_CHAIN2_KERNEL(zh_decode_c2_mid, C2Mid)
+ZH_CHAIN2_KERNEL(zh_decode_c2_max, C2Max)
 
-// spec: 1 min, 2 mid (zh_chain_spec.h ids).  Returns hipErrorInvalidValue for a spec this file has no kernel for.
+// spec: 1 min, 2 mid, 3 max (zh_chain_spec.h ids).  Returns hipErrorInvalidValue for a spec this file has no kernel for.
 extern "C" hipError_t zh_launch_chain2(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec) {
-  void (*k)(ZhLaunch) = spec == 1 ? zh_decode_c2_min : spec == 2 ? zh_decode_c2_mid : nullptr;
+  void (*k)(ZhLaunch) = spec == 1 ? zh_decode_c2_min : spec == 2 ? zh_decode_c2_mid : spec == 3 ? zh_decode_c2_max : nullptr;
   if (!k) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, stream, *L);
   return hipGetLastError();
 }
-extern "C" int zh_chain2_has(uint32_t spec) { return spec == 1 || spec == 2; }
+extern "C" int zh_chain2_has(uint32_t spec) { return spec >= 1 && spec <= 3; }

@@ -380,8 +380,12 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
   }
   // ---- specialisation the kernels may use (never changes results)
   if ((m.kind & 255u) == ZH_FAM_CHAIN) {
-    m.kind += zh_spec_lookup(hdr, len);                                  // ZH_FAM_CHAIN + {0 none, 1 min, 2 mid, 3 max}
-    m.kind |= zh_native_lookup(hdr + cp, m.hcomp_len) << 8;              // native HCOMP id or 0
+    uint32_t spec = zh_spec_lookup(hdr, len);                            // {0 none, 1 min, 2 mid, 3 max}
+    const uint32_t native = zh_native_lookup(hdr + cp, m.hcomp_len);     // native HCOMP id or 0
+    // zh_chain2.hip's max code relies on what the built-in HCOMP leaves in h[17..21] (zeros, and an even h[20])
+    if (spec == 3 && native != ZH_NATIVE_HCOMP_MAX) spec = 0;
+    m.kind += spec;
+    m.kind |= native << 8;
   }
   // Single direct CM whose HCOMP is "a<<= K  *d=a  halt" (D is 0 at every entry) with K >= 9: the low 9 bits of the
   // context hash are zero, which is what zh_cm.hip's compact window cache relies on.  Other single-CM models keep
