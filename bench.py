@@ -2,15 +2,23 @@
 """bench.py — decompress MB/s (bit-exact) on a multi-block ZPAQ stream, 1..8 MI355X.
 
 A "step" is one full decode pass (the hot path: arithmetic decode + component
-chain predict/update + ZPAQL HCOMP/PCOMP) over the rank's resident blocks.  The
-compressed stream is already in HBM when the timed region starts and the
-plaintext stays in HBM (PCIe-inclusive rates are in DESIGN.md, never `value`).
+chain predict/update + ZPAQL HCOMP/PCOMP) over the rank's shard of the blocks.
+The compressed stream is already in HBM when the timed region starts and the
+plaintext stays in HBM; the host-to-host (PCIe-inclusive) rate is reported
+beside it as `host_to_host`, never as `value`.
 
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
 256 x 4 MiB independent blocks per GPU, level-1 model (single direct order-1 CM),
-text-like synthetic plaintext "T".  Weak scaling: N GPUs decode N x 256 blocks;
-blocks are independent, so the only communication is the block work table and
-the per-block results (RCCL all_gather of a few KiB).
+text-like synthetic plaintext "T".  Weak scaling: N GPUs decode N x 256 blocks.
+
+N > 1 (BASELINE configs[3] layout): ONE shared stream and ONE block table.  Every
+rank writes 1/N of the blocks; the pieces are all-gathered into the shared stream
+(every rank holds it in HBM, as every rank would read the same archive), rank 0
+scans it and broadcasts the block/segment table, every rank derives the same
+longest-first plan (multigpu.lpt_assign) and decodes its shard with
+zpaqhip_decode_blocks_device(ids = shard); per-block results are all-gathered
+inside the timed region.  RCCL carries the table and the results only — no
+payload moves during decode (blocks are independent units).
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
   N>1:   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -18,9 +26,12 @@ Launch:  python bench.py [--gpus N --steps K --warmup W]
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -30,32 +41,41 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # Algorithmic HBM bytes per decoded plaintext byte, excluding stream I/O
-# (derivation repeated in DESIGN.md §5).
+# (derivation repeated in DESIGN.md §4).
 B_ALG = {"l1": 64, "min": 128, "mid": 842, "max": 3114}
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 HBM_COPY_GBPS = 6290.0          # same guide: measured copy peak (SURVEY.md §8d asks for both fractions)
+CLOCK_GHZ = 2.4                 # max shader clock (same guide)
+
+
+def source_hash():
+    """Identifies the kernels a PMC summary was taken with: SHA-1 over the sources of libzpaqhip."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "zpaqsharp_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(model, nb, bs):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/<round>/*_pmc_{FETCH,WRITE}_SIZE.csv, produced by tools/profile_bench.sh for this
-    exact workload): 2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half) + WRITE_SIZE, KB -> B.
-    None when no matching profile is committed."""
-    import csv
-    import glob
-    tag = f"{model}_{nb}x{bs >> 20}MiB"
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"*_{tag}_pmc_FETCH_SIZE.csv"))):
-        w = f.replace("FETCH_SIZE", "WRITE_SIZE")
-        if not os.path.exists(w):
-            continue
+    """HBM bytes per launch of the decode kernel from a committed rocprofv3 PMC summary
+    (profiles/<round>/pmc_<model>_<nb>x<KiB>KiB.json, written by tools/profile_bench.sh): FETCH_SIZE + WRITE_SIZE as the
+    counters report them (KB).  Only a summary taken with THESE sources counts; otherwise (None, reason)."""
+    tag = f"{model.replace('+', '_')}_{nb}x{bs >> 10}KiB"
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"pmc_{tag}.json")))
+    if not cands:
+        return None, "no PMC summary committed for this workload"
+    cur = source_hash()
+    for f in reversed(cands):
         try:
-            fe = float(next(csv.DictReader(open(f)))["value"])
-            wr = float(next(csv.DictReader(open(w)))["value"])
-        except (StopIteration, KeyError, ValueError):
+            d = json.load(open(f))
+        except (OSError, ValueError):
             continue
-        best = {"bytes": (2 * fe + wr) * 1024.0, "source": os.path.relpath(f, ROOT)}
-    return best
+        if d.get("src_hash") == cur:
+            return {"bytes": (float(d["FETCH_SIZE_KB"]) + float(d["WRITE_SIZE_KB"])) * 1024.0,
+                    "source": os.path.relpath(f, ROOT)}, None
+    return None, f"the committed PMC summaries were taken with other kernel sources than {cur}"
 
 
 def parse_args():
@@ -71,6 +91,10 @@ def parse_args():
                     help="blocks decoded by the CPU oracle for cpu_baseline (default: ~15 s of work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra figures of the N=1 line (host_to_host, all-core CPU, configs[2] / [4] shaped runs)")
+    ap.add_argument("--extras-block-bytes", type=int, default=512 << 10,
+                    help="block size of the configs[2] / configs[4] shaped extra runs (256 blocks each; full size = 4194304)")
     ap.add_argument("--gen-threads", type=int, default=None)
     ap.add_argument("--kernel", type=int, default=0, help="zpaqhip_opts.kernel (0 auto; 5 = round-1 chain kernels for min/mid/max)")
     ap.add_argument("--cache-dir", default=None, help="keep generated streams here and reuse them (profiling runs)")
@@ -80,13 +104,66 @@ def parse_args():
     return ap.parse_args()
 
 
+def make_stream(synth, model, model_name, kind, nb, bs, first_block, threads, cache_dir):
+    cache = os.path.join(cache_dir, f"{model_name}_{kind}_{nb}x{bs}_b{first_block}.npz") if cache_dir else None
+    if cache and os.path.exists(cache):
+        with np.load(cache) as f:
+            return f["stream"], f["offs"]
+    stream, offs = synth.stream(model, kind, nb, bs, first_block=first_block, threads=threads)
+    if cache:
+        os.makedirs(cache_dir, exist_ok=True)
+        np.savez(cache, stream=stream, offs=offs)
+    return stream, offs
+
+
+def roofline(base_model, kms, plain_bytes, rho, nb, bs, model_tag):
+    b_alg = B_ALG[base_model] + 1 + rho
+    achieved = b_alg * plain_bytes / (kms * 1e-3) / 1e9
+    tr, why = pmc_traffic(model_tag, nb, bs)
+    waves = int(min(nb, 256))
+    return {"bound": "issue",                 # one bit-serial wave (two for a single CM) per block: see "issue" and DESIGN.md §4
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
+            "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
+            "traffic_note": why or "FETCH_SIZE + WRITE_SIZE as the counters report them (KB); gfx950 may count 16-B/lane reads at half",
+            "measured_hbm_gbps": (tr["bytes"] / (kms * 1e-3) / 1e9) if tr else None,
+            "algorithmic_bytes_per_launch": b_alg * plain_bytes, "alg_bytes_per_plain_byte": b_alg,
+            "kernel_ms": kms,
+            "issue": {"blocks_in_flight": waves,
+                      "cycles_per_plain_byte_per_block": kms * 1e-3 * CLOCK_GHZ * 1e9 / (plain_bytes / waves),
+                      "note": "the operative bound is the dependent instruction chain of the wave that owns a block; "
+                              "the HBM fraction above is kept for reference (traffic is far below algorithmic bytes where tables live in LDS)"}}
+
+
+def resident_run(z, synth, torch, ctx, dev, model_name, kind, nb, bs, threads, cache_dir):
+    """One GPU, one decode pass over a resident stream: (MB/s, kernel_ms, rho, bit_exact, stats)."""
+    from zpaqsharp_amd import models
+    stream, _ = make_stream(synth, models.get(model_name), model_name, kind, nb, bs, 0, threads, cache_dir)
+    sc = z.scan(stream)
+    d_in = torch.from_numpy(stream).to(dev)
+    d_out = torch.zeros(nb * bs, dtype=torch.uint8, device=dev)
+    off, cap = [i * bs for i in range(nb)], [bs] * nb
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rc, res = ctx.decode_blocks_device(d_in.data_ptr(), stream.size, sc, d_out.data_ptr(), off, cap, h_in=stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    ok = all(r.status == 0 and r.out_len == bs for r in res)
+    if ok:
+        got = d_out.cpu().numpy()
+        ok = all(np.array_equal(got[b * bs:(b + 1) * bs], synth.plain(kind, b, bs)) for b in range(nb))
+    rho = sum(s.data_len for s in sc.segments) / (nb * bs)
+    return nb * bs / dt / 1e6, float(st.kernel_ms), rho, ok, st
+
+
 def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
 
     import zpaqsharp_amd as z
-    from zpaqsharp_amd import models, synth
+    from zpaqsharp_amd import models, multigpu, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -114,45 +191,27 @@ def main():
     kind = args.kind or ("X" if "+e8e9" in model_name else "T")
     nb, bs = args.blocks, args.block_bytes
     model = models.get(model_name)
-
-    # ---- this rank's shard of the job: global blocks [rank*nb, (rank+1)*nb)
     ncpu = os.cpu_count() or 1
     gen_threads = args.gen_threads or max(1, min(32, ncpu // max(1, min(world, 8))))
+
+    # ---- the shared stream: this rank writes global blocks [rank*nb, (rank+1)*nb)
     t0 = time.time()
-    cache = os.path.join(args.cache_dir, f"{model_name}_{kind}_{nb}x{bs}_r{rank}.npz") if args.cache_dir else None
-    if cache and os.path.exists(cache):
-        with np.load(cache) as f:
-            stream, offs = f["stream"], f["offs"]
-    else:
-        stream, offs = synth.stream(model, kind, nb, bs, first_block=rank * nb, threads=gen_threads)
-        if cache:
-            os.makedirs(args.cache_dir, exist_ok=True)
-            np.savez(cache, stream=stream, offs=offs)
+    part, _ = make_stream(synth, model, model_name, kind, nb, bs, rank * nb, gen_threads, args.cache_dir)
     gen_s = time.time() - t0
-    sc = z.scan(stream)
-    assert sc.n_blocks == nb, (sc.n_blocks, nb)
-    plain_bytes = nb * bs
-    coded_bytes = int(sum(s.data_len for s in sc.segments))
-    rho = coded_bytes / plain_bytes
-
     ctx = z.Context(local_rank)
-    d_in = torch.from_numpy(stream).to(dev)
-    d_out = torch.zeros(plain_bytes, dtype=torch.uint8, device=dev)
-    out_off = [i * bs for i in range(nb)]
-    out_cap = [bs] * nb
-
-    # ---- work table over RCCL: every rank learns every block's weight; the plan is
-    # static (a block is decoded where it is resident), so no payload moves.
-    weights = np.array([sc.segments[b.first_seg].data_len for b in sc.blocks], dtype=np.int64)
     if world > 1:
-        from zpaqsharp_amd import multigpu
-        all_w = multigpu.all_gather_table(weights, dist, coll_dev)
-        assert all_w.shape == (world, nb)
+        job = multigpu.ShardedJob.from_parts(ctx, part, dist, dev, coll_dev)   # all-gather pieces, scan on rank 0, broadcast table, plan
+    else:
+        job = multigpu.ShardedJob.single(ctx, part, dev)
+    n_glob = job.sc.n_blocks
+    assert n_glob == nb * world, (n_glob, nb, world)
+    mine = job.shard
+    d_out = torch.zeros(max(1, len(mine)) * bs, dtype=torch.uint8, device=dev)
+    out_off = [i * bs for i in range(len(mine))]
+    out_cap = [bs] * len(mine)
 
     def step():
-        rc, res = ctx.decode_blocks_device(d_in.data_ptr(), stream.size, sc, d_out.data_ptr(), out_off, out_cap,
-                                           h_in=stream, kernel=args.kernel)
-        return res
+        return job.decode(d_out, out_off, out_cap, kernel=args.kernel)         # HIP decode of the shard (+ all_gather of the results)
 
     def barrier():
         if world > 1:
@@ -165,7 +224,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
+        table = step()
         kernel_ms.append(ctx.stats().kernel_ms)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -175,23 +234,20 @@ def main():
         elapsed = float(t.item())
     st = ctx.stats()
 
-    # ---- bit-exact check of the last step's output against the generator's plaintext
-    ok = all(r.status == 0 and r.out_len == bs for r in res)
+    # ---- bit-exact check of the last step's output against the generator's plaintext (global block ids)
+    ok = bool((table[:, 0] == 0).all() and (table[:, 1] == bs).all())
     if not args.no_verify:
         got = d_out.cpu().numpy()
-        for b in range(nb):
-            exp = synth.plain(kind, rank * nb + b, bs)
-            if not np.array_equal(got[b * bs:(b + 1) * bs], exp):
+        for j, b in enumerate(mine):
+            if not np.array_equal(got[j * bs:(j + 1) * bs], synth.plain(kind, b, bs)):
                 ok = False
                 break
-    okv = np.array([int(ok), plain_bytes, coded_bytes], dtype=np.int64)
+    coded_bytes = int(sum(s.data_len for s in job.sc.segments))
+    total_plain = n_glob * bs
     if world > 1:
-        from zpaqsharp_amd import multigpu
-        allv = multigpu.all_gather_table(okv, dist, coll_dev)
-        ok = bool(allv[:, 0].all())
-        total_plain = int(allv[:, 1].sum())
-    else:
-        total_plain = plain_bytes
+        allv = multigpu.all_gather_table(np.array([int(ok)], dtype=np.int64), dist, coll_dev)
+        ok = bool(allv.all())
+    rho = coded_bytes / total_plain
 
     if rank != 0:
         if world > 1:
@@ -201,23 +257,69 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_plain * args.steps / elapsed / 1e6
     kms = float(np.mean(kernel_ms))
-    b_alg = B_ALG[base] + 1 + rho
-    achieved = b_alg * plain_bytes / (kms * 1e-3) / 1e9
 
     cpu = None
+    extras = {}
+    block_start = [int(b.tag_off) for b in job.sc.blocks] + [job.stream_len]
     if not args.no_cpu_baseline:
         import oracle
         # bounded sample of the SAME stream: first S blocks, one host thread.
         per_block_guess = bs / 9e6 if base == "l1" else bs / 1.5e6
         S = args.cpu_sample_blocks or max(1, min(nb, int(15.0 / per_block_guess)))
-        sample = stream[:int(offs[S])].tobytes()
+        sample = job.h_stream[:block_start[S]].tobytes()
         t0 = time.perf_counter()
         out = oracle.decompress(sample, cap=S * bs + 16)
         dt = time.perf_counter() - t0
         assert len(out) == S * bs
         cpu = {"value": S * bs / dt / 1e6, "unit": "MB/s", "cores": 1, "kind": "port",
-               "sample": f"first {S} of {nb} blocks ({S * bs >> 20} MiB plaintext) of the same stream, "
+               "sample": f"first {S} of {n_glob} blocks ({S * bs >> 20} MiB plaintext) of the same stream, "
                          f"oracle/zpaq_oracle.c -O2, 1 thread, host has {ncpu} logical cores"}
+        if world == 1 and not args.no_extras:
+            # all the host cores one GPU's share of the box offers (SURVEY §8d ii): blocks spread over threads
+            T = max(1, min(16, ncpu))
+            per = max(1, S // 4)
+            pieces = []
+            for i in range(T):
+                b0 = (i * per) % max(1, n_glob - per + 1)
+                pieces.append(job.h_stream[block_start[b0]:block_start[b0 + per]].tobytes())
+            done = [0] * T
+
+            def work(i):
+                done[i] = len(oracle.decompress(pieces[i], cap=per * bs + 16))      # ctypes releases the GIL
+            th = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+            t0 = time.perf_counter()
+            [t.start() for t in th]
+            [t.join() for t in th]
+            dt = time.perf_counter() - t0
+            extras["cpu_all_cores"] = {"value": sum(done) / dt / 1e6, "unit": "MB/s", "threads": T,
+                                       "sample": f"{T} threads x {per} block(s) of the same stream, one oracle instance per thread"}
+
+    if world == 1 and not args.no_extras:
+        # host buffer -> host buffer through zpaqhip_decompress (scan + H2D + kernel + D2H), pinned memory
+        h_in = torch.from_numpy(job.h_stream).pin_memory()
+        h_out = torch.empty(total_plain, dtype=torch.uint8).pin_memory()
+        ctx.decompress_into(h_in.numpy(), h_out.numpy())                     # warm-up (allocations)
+        t0 = time.perf_counter()
+        n = ctx.decompress_into(h_in.numpy(), h_out.numpy())
+        dt = time.perf_counter() - t0
+        s2 = ctx.stats()
+        extras["host_to_host"] = {"value": n / dt / 1e6, "unit": "MB/s", "memory": "pinned",
+                                  "fraction_of_resident_rate": (n / dt / 1e6) / value if value else None,
+                                  "h2d_ms": s2.h2d_ms, "kernel_ms": s2.kernel_ms, "d2h_ms": s2.d2h_ms, "launches": int(s2.launches),
+                                  "bit_exact": bool(n == total_plain and np.array_equal(h_out.numpy()[-bs:], synth.plain(kind, n_glob - 1, bs)))}
+        del h_in, h_out
+        # BASELINE configs[2] (mid) and configs[4] (max + the reference's E8E9 PCOMP) shaped runs, 256 blocks each
+        if model_name == "l1":
+            ebs = args.extras_block_bytes
+            for mname, mkind in (("mid", "T"), ("max+e8e9", "X")):
+                v, k, r, okx, sx = resident_run(z, synth, torch, ctx, dev, mname, mkind, 256, ebs, gen_threads, args.cache_dir)
+                extras.setdefault("other_configs", []).append({
+                    "config": "BASELINE configs[2]" if mname == "mid" else "BASELINE configs[4]",
+                    "workload": f"256 x {ebs >> 10} KiB blocks, model {mname}, plaintext {mkind}"
+                                + ("" if ebs == 4 << 20 else " (block size reduced so that the default run stays within minutes; "
+                                   "full-size runs: profiles/)"),
+                    "value": v if okx else 0.0, "unit": "MB/s", "bit_exact": bool(okx), "kernel_kind": int(sx.kernel_kind),
+                    "roofline": roofline(mname.split("+")[0], k, 256 * ebs, r, 256, ebs, mname)})
 
     line = {
         "metric": "decompress MB/s (bit-exact) on 1 GiB multi-block stream",
@@ -226,23 +328,22 @@ def main():
         "dtype": "u32", "data": "synthetic",
         "bit_exact": bool(ok),
         "config": {
-            "workload": f"BASELINE configs[1]: {nb} x {bs >> 20} MiB independent blocks per GPU, "
+            "workload": f"BASELINE configs[{1 if base in ('l1', 'min') else 2 if base == 'mid' else 4}]"
+                        + (f" x{world} GPUs (configs[3] layout: one shared stream + block table)" if world > 1 else "")
+                        + f": {nb} x {bs >> 20} MiB independent blocks per GPU, "
                         f"model {model_name} ({model.n} component(s)), plaintext generator {kind}",
             "zpaq_model": model_name, "blocks_per_gpu": nb, "block_bytes": bs, "plaintext": kind,
-            "coded_over_plain": round(rho, 4), "parallelism": f"blocks x{world} (no data-path collective)",
+            "coded_over_plain": round(rho, 4),
+            "parallelism": (f"blocks x{world}: shared stream, broadcast table, LPT plan, ids-sharded HIP decode, all_gather of results"
+                            if world > 1 else "blocks x1"),
             "kernel_kind": int(st.kernel_kind), "blocks_in_flight": int(st.concurrent),
+            "shard_blocks": [len(s) for s in job.plan],
         },
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS,
-                     "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
-                     "traffic": (pmc_traffic(model_name, nb, bs) or {}).get("bytes"),
-                     "traffic_source": (pmc_traffic(model_name, nb, bs) or {}).get("source"),
-                     "algorithmic_bytes_per_launch": b_alg * plain_bytes,
-                     "kernel_ms": kms, "alg_bytes_per_plain_byte": b_alg,
-                     "note": "bit-serial chain bound by single-wave instruction issue, not by HBM; see DESIGN.md §4"},
+        "roofline": roofline(base, kms, len(mine) * bs, rho, len(mine), bs, model_name),
         "cpu_baseline": cpu,
         "gen_seconds": round(gen_s, 1),
     }
+    line.update(extras)
     if not ok:
         line["value"] = 0.0
         line["error"] = "GPU output is not bit-exact"

@@ -225,3 +225,22 @@ def test_full_size_blocks_of_the_chain_models(ctx, model, kind):
     assert got.size == nb * bs
     for b in range(nb):
         assert np.array_equal(got[b * bs:(b + 1) * bs], synth.plain(kind, 1000 + b, bs)), b
+
+
+def test_two_ranks_on_one_gpu_run_the_sharded_hip_decode(tmp_path):
+    """bench.py's N > 1 path — shared stream, broadcast table, LPT plan, zpaqhip_decode_blocks_device(ids = shard),
+    all_gather of the results — rehearsed with two gloo ranks that share this box's one GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", WORLD_SIZE="2")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--share-gpu", "--model", "mid",
+           "--blocks", "5", "--block-bytes", "40000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--gen-threads", "2"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1].decode()[-2000:] for o in outs]
+    line = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    assert line["bit_exact"] is True and line["n_gpus"] == 2 and line["value"] > 0
+    assert sorted(line["config"]["shard_blocks"]) == [5, 5] and line["config"]["kernel_kind"] == 3

@@ -79,6 +79,18 @@ assert list(table[:, 2]) == want
 assert sorted(sum(shards, [])) == list(range(7)) and all(len(s) >= 3 for s in shards)
 bt = multigpu.broadcast_table(np.array(weights if dist.get_rank() == 0 else [0] * 7), dist)
 assert list(bt) == weights
+# the product's job object: each rank contributes its piece of the shared stream, rank 0 scans, the table is broadcast
+rank = dist.get_rank()
+cut = int(offs[4])
+part = stream[:cut] if rank == 0 else stream[cut:]
+job = multigpu.ShardedJob.from_parts(None, part, dist, None)
+assert job.stream_len == stream.size and np.array_equal(job.h_stream, stream)
+assert job.sc.n_blocks == 7 and [int(b.tag_off) for b in job.sc.blocks] == [int(b.tag_off) for b in sc.blocks]
+assert job.plan == multigpu.lpt_assign(weights, 2) and job.shard == job.plan[rank]
+def fake(ids):        # CPU stand-in for the HIP decode of a shard
+    return [[0, len(oracle.decompress(stream[int(offs[b]):int(offs[b + 1])].tobytes()))] for b in ids]
+t2 = job.decode(None, None, None, decode_fn=fake)
+assert t2.shape == (7, 2) and list(t2[:, 0]) == [0] * 7 and list(t2[:, 1]) == [3000] * 7
 dist.destroy_process_group()
 print("rank ok")
 '''

@@ -23,7 +23,9 @@ sys.path.insert(0, ROOT)
 
 from zpaqsharp_amd import models, zpaql  # noqa: E402
 
-SRC = ["a", "b", "c", "d", "(uint32_t)M[b & mmask]", "(uint32_t)M[c & mmask]", "H[d & hmask]"]
+# Every value of a ZPAQL machine is wave-uniform on the device; ZH_UNI (v_readfirstlane) tells the compiler so at the
+# places where it cannot see it (function entry, memory reads), and the whole program then runs on the scalar unit.
+SRC = ["a", "b", "c", "d", "ZH_UNI((uint32_t)M[b & mmask])", "ZH_UNI((uint32_t)M[c & mmask])", "ZH_UNI(H[d & hmask])"]
 ALU = ["a += {s};", "a -= {s};", "a *= {s};", "{{ uint32_t s_ = {s}; a = s_ ? a / s_ : 0; }}",
        "{{ uint32_t s_ = {s}; a = s_ ? a % s_ : 0; }}", "a &= {s};", "a &= ~({s});", "a |= {s};", "a ^= {s};",
        "a <<= (({s}) & 31);", "a >>= (({s}) & 31);", "f = a == ({s});", "f = a < ({s});", "f = a > ({s});"]
@@ -83,7 +85,8 @@ def translate(code: bytes, name: str) -> str:
            "template <class MP, class HP>",
            f"ZH_HD inline __attribute__((always_inline)) int zh_native_{name}(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, uint32_t &f, uint32_t input,",
            "    MP M, uint32_t mmask, HP H, uint32_t hmask, uint32_t *R, zhcore::Sink *out, uint64_t budget) {",
-           "  a = input;", "  (void)R; (void)out; (void)budget; (void)f;"]
+           "  a = ZH_UNI(input); b = ZH_UNI(b); c = ZH_UNI(c); d = ZH_UNI(d); f = ZH_UNI(f);",
+           "  (void)R; (void)out; (void)budget; (void)f;"]
     for pc in starts:
         op = code[pc]
         arg = code[pc + 1] if pc + 1 < n else 0
@@ -94,7 +97,7 @@ def translate(code: bytes, name: str) -> str:
             if x == 7:
                 off = ((arg + 128) & 255) - 128
                 if ddd < 4:
-                    st = f"{'abcd'[ddd]} = R[{arg}];"
+                    st = f"{'abcd'[ddd]} = ZH_UNI(R[{arg}]);"
                 elif ddd == 4:
                     st = f"if (f) {{ {jump(nxt + off, pc)} }}"
                 elif ddd == 5:
@@ -105,8 +108,8 @@ def translate(code: bytes, name: str) -> str:
                     st = jump(nxt + off, pc)
             elif ddd == 7:
                 st = {0: "return 0;", 1: "if (out) zhcore::sink_put(*out, a & 255);",
-                      3: "a = (a + M[b & mmask] + 512u) * 773u;",
-                      4: "H[d & hmask] = (H[d & hmask] + a + 512u) * 773u;"}.get(x, "return ZH_E_ZPAQL;")
+                      3: "a = (a + ZH_UNI((uint32_t)M[b & mmask]) + 512u) * 773u;",
+                      4: "H[d & hmask] = (ZH_UNI(H[d & hmask]) + a + 512u) * 773u;"}.get(x, "return ZH_E_ZPAQL;")
             elif x > 4 or op == 0:
                 st = "return ZH_E_ZPAQL;"
             else:
@@ -146,7 +149,9 @@ def main():
     lines = ["// zh_zpaql_native.h — GENERATED by tools/gen_zpaql_native.py from zpaqsharp_amd/models.py; do not edit.",
              "// Native (ahead-of-time translated) forms of the ZPAQL programs this repo knows; see the generator.",
              "#pragma once", "#include <stdint.h>", "#include <string.h>", "", '#include "zh_core.h"', "",
-             "#if defined(__HIPCC__)", "#pragma clang diagnostic push", '#pragma clang diagnostic ignored "-Wunused-label"', "#endif", ""]
+             "#if defined(__HIPCC__)", "#pragma clang diagnostic push", '#pragma clang diagnostic ignored "-Wunused-label"', "#endif",
+             "#if defined(__HIP_DEVICE_COMPILE__)", "#define ZH_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))", "#else",
+             "#define ZH_UNI(x) ((uint32_t)(x))", "#endif", ""]
     for name, code in items:
         lines.append(translate(code, name))
         lines.append("")

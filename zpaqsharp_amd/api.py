@@ -149,6 +149,15 @@ class Context:
             _raise(err, rc)
         return out[:n.value]
 
+    def decompress_into(self, stream: np.ndarray, out: np.ndarray, **opt) -> int:
+        """zpaqhip_decompress on caller-owned host buffers (e.g. pinned memory): returns the plaintext length."""
+        o = make_opts(**opt)
+        err, n = Err(), C.c_size_t(0)
+        rc = self._L.zpaqhip_decompress(self._h, stream.ctypes.data, stream.size, out.ctypes.data, out.size, C.byref(n), C.byref(o), C.byref(err))
+        if rc:
+            _raise(err, rc)
+        return n.value
+
     def block_pcomp(self, stream, block: int) -> bytes:
         """Decompresser.pcomp() (Decompresser.cs:155-158): b"" if block `block` has no PCOMP, else
         length-lo, length-hi, program bytes (ZPAQL.write(out, true), ZPAQL.cs:171-177)."""

@@ -23,7 +23,7 @@ extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, uint32_t grid, hipStream_t
 extern "C" hipError_t zh_launch_sha1(const uint8_t *data, const uint64_t *seg, uint32_t n_seg, uint32_t *digest, hipStream_t stream);
 extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof);
 extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
-extern "C" hipError_t zh_launch_chain2(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec);
+extern "C" hipError_t zh_launch_chain2(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof);
 extern "C" int zh_chain2_has(uint32_t spec);
 
 
@@ -172,25 +172,38 @@ int zpaqhip_read_device_tables(zpaqhip_ctx *c, uint16_t *squash, int16_t *stretc
   return ZPAQHIP_OK;
 }
 
+}  // extern "C"
+
 // `h_hdrs`: the block headers are needed on the host to build the model
 // descriptors; they are fetched from the device stream (a few hundred bytes per
 // distinct model) so the ABI stays a pure device-buffer interface.
-int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, size_t in_len,
+// The call has two halves so that the whole-stream forms can keep the host busy (callbacks, scanning, copies of the
+// neighbouring batches) while a batch's kernels run: decode_launch() enqueues everything on `stream` and returns,
+// decode_finish() waits for the stream and turns the device results into zpaqhip_seg_result records.  One launch may be
+// outstanding per context (the descriptor / result / arena buffers belong to the context).
+struct zh_pending {
+  std::vector<uint32_t> sel;
+  const zpaqhip_block *blocks = nullptr;
+  const zpaqhip_segment *segs = nullptr;
+  size_t n_segs = 0;
+  hipStream_t stream = nullptr;
+  uint64_t total_in = 0, total_model = 0;
+  uint32_t launches = 0, slots = 0, kind_used = 0;
+  bool prof = false, active = false;
+};
+
+static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, size_t in_len,
                                  const zpaqhip_block *blocks,
                                  size_t n_blocks, const zpaqhip_segment *segs, size_t n_segs, const uint32_t *ids,
                                  size_t n_ids, void *d_out, const uint64_t *out_off, const uint64_t *out_cap,
-                                 zpaqhip_seg_result *results, const zpaqhip_opts *opts_in, void *hip_stream,
+                                 const zpaqhip_opts &opts, hipStream_t stream, zh_pending &P,
                                  zpaqhip_err *err) {
-  if (!c || !blocks || !segs || !results || (!d_in && in_len) || (ids == nullptr && n_ids != 0 && n_ids != n_blocks)) {
-    set_err(err, ZPAQHIP_E_ARG, -1, -1);
-    return ZPAQHIP_E_ARG;
-  }
-  const zpaqhip_opts opts = resolve_opts(opts_in);
+  P = zh_pending();
+  P.blocks = blocks; P.segs = segs; P.n_segs = n_segs; P.stream = stream;
   HIPCHK(hipSetDevice(c->device));
-  hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
   memset(&c->stats, 0, sizeof c->stats);
 
-  std::vector<uint32_t> sel;
+  std::vector<uint32_t> &sel = P.sel;
   if (ids) sel.assign(ids, ids + n_ids);
   else { sel.resize(n_blocks); std::iota(sel.begin(), sel.end(), 0u); }
   if (sel.empty()) return ZPAQHIP_OK;
@@ -325,8 +338,8 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     if (prof) L.debug = (uint64_t *)((uint8_t *)c->queue.p + kQueueBytes);
     if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, slots_of[g], stream));
     else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, slots_of[g], stream));
-    else if (g > ZH_FAM_CHAIN && zh_chain2_has(g - ZH_FAM_CHAIN) && opts.kernel != 5 && !prof)   // per-model bit loop (zh_chain2.hip)
-      HIPCHK(zh_launch_chain2(&L, slots_of[g], stream, g - ZH_FAM_CHAIN));
+    else if (g > ZH_FAM_CHAIN && zh_chain2_has(g - ZH_FAM_CHAIN) && opts.kernel != 5)   // per-model bit loop (zh_chain2.hip)
+      HIPCHK(zh_launch_chain2(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));
     else if (g >= ZH_FAM_CHAIN) HIPCHK(zh_launch_chain(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));
     else HIPCHK(zh_launch_generic(&L, slots_of[g], stream));
     ++launches;
@@ -334,7 +347,24 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
     kind_used = std::max(kind_used, std::min(g, (uint32_t)ZH_FAM_CHAIN) + 1);
   }
   HIPCHK(hipEventRecord(c->ev1, stream));
-  if (getenv("ZPAQHIP_PROF")) {
+  P.total_in = total_in; P.total_model = total_model;
+  P.launches = launches; P.slots = slots; P.kind_used = kind_used;
+  P.prof = getenv("ZPAQHIP_PROF") != nullptr;
+  P.active = true;
+  return ZPAQHIP_OK;
+}
+
+static int decode_finish(zpaqhip_ctx *c, zh_pending &P, zpaqhip_seg_result *results, zpaqhip_err *err) {
+  if (!P.active) return ZPAQHIP_OK;                     // nothing was selected
+  P.active = false;
+  const std::vector<uint32_t> &sel = P.sel;
+  const zpaqhip_block *blocks = P.blocks;
+  const zpaqhip_segment *segs = P.segs;
+  const size_t n_segs = P.n_segs;
+  hipStream_t stream = P.stream;
+  const uint64_t total_in = P.total_in, total_model = P.total_model;
+  const uint32_t launches = P.launches, slots = P.slots, kind_used = P.kind_used;
+  if (P.prof) {
     uint64_t dbg[8];
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipMemcpy(dbg, (uint8_t *)c->queue.p + kQueueBytes, 64, hipMemcpyDeviceToHost));
@@ -385,7 +415,24 @@ int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t
   return first_bad;
 }
 
-}  // extern "C"
+extern "C" int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, size_t in_len,
+                                 const zpaqhip_block *blocks,
+                                 size_t n_blocks, const zpaqhip_segment *segs, size_t n_segs, const uint32_t *ids,
+                                 size_t n_ids, void *d_out, const uint64_t *out_off, const uint64_t *out_cap,
+                                 zpaqhip_seg_result *results, const zpaqhip_opts *opts_in, void *hip_stream,
+                                 zpaqhip_err *err) {
+  if (!c || !blocks || !segs || !results || (!d_in && in_len) || (ids == nullptr && n_ids != 0 && n_ids != n_blocks)) {
+    set_err(err, ZPAQHIP_E_ARG, -1, -1);
+    return ZPAQHIP_E_ARG;
+  }
+  const zpaqhip_opts opts = resolve_opts(opts_in);
+  zh_pending P;
+  int rc = decode_launch(c, d_in, h_in, in_len, blocks, n_blocks, segs, n_segs, ids, n_ids, d_out, out_off, out_cap, opts,
+                         hip_stream ? (hipStream_t)hip_stream : c->stream, P, err);
+  if (rc) return rc;
+  return decode_finish(c, P, results, err);
+}
+
 
 // ---------------------------------------------------------------------------
 // Whole-stream forms

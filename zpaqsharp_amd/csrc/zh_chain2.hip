@@ -125,10 +125,59 @@ __device__ __forceinline__ int wrlane_c(int park, int val) {
   return park;
 }
 
+// HCOMP's M array in registers (the three models have 2^hm <= 512 bytes): byte i is byte (i & 3) of lane (i >> 2) & 63
+// of v[i >> 8].  A `hash` instruction (a = (a + M[b] + 512) * 773) then costs a v_readlane and a bit-field extract
+// instead of a dependent LDS round trip; seven of them in a row are mid's whole program.
+template <int NREG>
+struct MRegs { uint32_t v[NREG]; };
+template <int NREG>
+struct MByteRef {
+  MRegs<NREG> *m;
+  uint32_t i;
+  __device__ __forceinline__ operator uint32_t() const {
+    const uint32_t ln = (i >> 2) & 63u;
+    uint32_t w = rdlane(m->v[0], ln);
+    if (NREG > 1) { const uint32_t w1 = rdlane(m->v[NREG > 1 ? 1 : 0], ln); w = (i >> 8) & 1u ? w1 : w; }
+    return (w >> ((i & 3u) * 8u)) & 255u;
+  }
+  __device__ __forceinline__ MByteRef &operator=(uint32_t x) {
+    const uint32_t ln = (i >> 2) & 63u, sh = (i & 3u) * 8u;
+    if (NREG > 1 && ((i >> 8) & 1u)) {
+      const uint32_t w = rdlane(m->v[NREG > 1 ? 1 : 0], ln);
+      m->v[NREG > 1 ? 1 : 0] = wrlane((w & ~(255u << sh)) | (x & 255u) << sh, ln, m->v[NREG > 1 ? 1 : 0]);
+    } else {
+      const uint32_t w = rdlane(m->v[0], ln);
+      m->v[0] = wrlane((w & ~(255u << sh)) | (x & 255u) << sh, ln, m->v[0]);
+    }
+    return *this;
+  }
+};
+template <int NREG>
+struct MView {
+  MRegs<NREG> *m;
+  __device__ __forceinline__ MByteRef<NREG> operator[](uint32_t i) const { return MByteRef<NREG>{m, i}; }
+};
+
 constexpr uint32_t kOob = 0x80000000u;        // buffer offset beyond every arena slot of this family (< 2 GiB): dropped
 
-template <class SP>
+// Diagnostic build (PROF): cycles per stage, summed per block into L.debug[0..7].  Stamps wait for LDS/scalar results
+// only (global memory stays in flight, as in the real kernel).
+#define C2_STAMP(i)                                                                                  \
+  do {                                                                                               \
+    if (PROF) {                                                                                      \
+      uint64_t now_;                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+      prof[i] += now_ - tprev;                                                                       \
+      tprev = now_;                                                                                  \
+    }                                                                                                \
+  } while (0)
+
+template <class SP, bool PROF>
 __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) {
+  uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t tprev = 0;
   const uint32_t lane = threadIdx.x;
   constexpr uint64_t kII = SP::icm | SP::isse;
   const bool l_isse = (SP::isse >> lane) & 1, l_ii = (kII >> lane) & 1;
@@ -278,6 +327,10 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
     const uint32_t hmask = hz.hmask;
     const uint32_t hnative = (uni(M->kind) >> 8) & 255;
     uint32_t ha = 0, hb = 0, hc = 0, hd = 0, hf = 0;
+    constexpr int kMRegs = SP::id == 3 ? 2 : 1;
+    MRegs<kMRegs> mregs;
+    for (int i = 0; i < kMRegs; ++i) mregs.v[i] = 0;
+    const MView<kMRegs> reg_m{&mregs};                   // M of the native programs (hm <= 8 + log2 kMRegs, checked by the host)
     const lds_u8_p lds_m = (lds_u8_p)lds_off(S.mreg);
     const lds_u32_p lds_h = (lds_u32_p)lds_off(S.hreg);
 
@@ -434,12 +487,14 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
           // ======== one bit.  NODE = position in the nibble (0..3); the node index is hm (1, 2-3, 4-7, 8-15).
           uint32_t hm = 1;
           uint32_t pairS = 0;                            // bit histories of nodes 2hm, 2hm+1
+          Probe spec[4];                                 // candidate rows of the second nibble
           l0_direct();
 #pragma unroll
           for (int bit = 0; bit < 8; ++bit) {
             const bool pre_ii = (bit & 3) != 3;          // the next bit stays in this nibble: fetch both of its nodes
             const bool pre_mx = bit != 7;                // the next bit stays in this byte: fetch both of its mixer rows
             hm = uni(hm); c8 = uni(c8);
+            if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
             // ---- (a) requests for the NEXT bit, both ways
             uint32_t ea0 = 0, ea1 = 0;
             v2u e0 = {0, 0}, e1 = e0;
@@ -480,21 +535,26 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
             }
 #pragma unroll
             for (uint32_t t = 0; t < SP::depth; ++t) p = med3i((__mul24(shr1(p), cw0) + cw1m) >> 16, -2048, 2047);
+            C2_STAMP(0);
             // ---- (c) mixers
             int p15 = 0, p16 = 0, p17 = 0, p18 = 0, p19 = 0, p20 = 0;       // max: the serial tail runs on the scalar unit
             uint32_t sel18 = 0, sel20 = 0, ti18 = 0, ti20 = 0;
             int dtv18 = 0, dtv20 = 0;
             if constexpr (SP::id == 3) {
               // MIX 15 over lanes 0-14, MIX 16 over lanes 0-15 (Predictor.cs:302-316): row sums land in lane 15
+              // (the two row sums are independent up to MIX 16's last input, which is MIX 15's output: they interleave)
+              const int w1hi = mw[1] >> 8;
               int t0 = __mul24(mw[0] >> 8, p);
-              t0 += dpp_shr(t0, 1); t0 += dpp_shr(t0, 2); t0 += dpp_shr(t0, 4); t0 += dpp_shr(t0, 8);
+              int t1 = lane == 15u ? 0 : __mul24(w1hi, p);
+              t0 += dpp_shr(t0, 1); t1 += dpp_shr(t1, 1);
+              t0 += dpp_shr(t0, 2); t1 += dpp_shr(t1, 2);
+              t0 += dpp_shr(t0, 4); t1 += dpp_shr(t1, 4);
+              t0 += dpp_shr(t0, 8); t1 += dpp_shr(t1, 8);
               p15 = med3i((int)rdlane((uint32_t)t0, 15) >> 8, -2048, 2047);
-              p = wrlane_c<15>(p, p15);
-              int t1 = __mul24(mw[1] >> 8, p);
-              t1 += dpp_shr(t1, 1); t1 += dpp_shr(t1, 2); t1 += dpp_shr(t1, 4); t1 += dpp_shr(t1, 8);
-              p16 = med3i((int)rdlane((uint32_t)t1, 15) >> 8, -2048, 2047);
+              p = lane == 15u ? p15 : p;
+              p16 = med3i(((int)rdlane((uint32_t)t1, 15) + (int)rdlane((uint32_t)w1hi, 15) * p15) >> 8, -2048, 2047);
               p17 = (w17 * p15 + (65536 - w17) * p16) >> 16;                 // MIX2 17 (Predictor.cs:291-301)
-              auto sse = [&](int pin, uint32_t rowv, int &pout, uint32_t &sel, uint32_t &ti, int &dtv) __attribute__((always_inline)) {
+              auto sse = [&](int pin, uint32_t rowv, int &pout, uint32_t &sel, uint32_t &ti, int &dtv) __attribute__((always_inline)) {   // dtv: per-lane copy, made scalar in update()
                 int pq = pin + 992;                                          // SSE (Predictor.cs:327-340)
                 pq = pq < 0 ? 0 : pq > 1983 ? 1983 : pq;
                 const uint32_t wt = (uint32_t)pq & 63u, iq = (uint32_t)pq >> 6;
@@ -503,16 +563,16 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
                 pout = stretch_u(((e0 >> 10) * (64u - wt) + (e1 >> 10) * wt) >> 13);
                 sel = (wt >> 5) ? e1 : e0;                                   // the entry train() will update
                 ti = iq + (wt >> 5);
-                dtv = (int)uni((uint32_t)S.dt[sel & 0x3ffu]);
+                dtv = S.dt[sel & 0x3ffu];                                    // wanted only after the bit is known
               };
               sse(p17, row18, p18, sel18, ti18, dtv18);
               p19 = (int)((int)w19 * p17 + (65536 - (int)w19) * p18) >> 16;  // MIX2 19
               sse(p19, row20, p20, sel20, ti20, dtv20);
               const int p21 = (w21 * p19 + (65536 - w21) * p20) >> 16;       // MIX2 21
-              p = wrlane_c<16>(p, p16);
-              p = wrlane_c<17>(p, p17);
-              p = wrlane_c<19>(p, p19);
-              p = wrlane_c<21>(p, p21);                   // lanes 18 and 20 (SSE) need no squash
+              p = lane == 16u ? p16 : p;
+              p = lane == 17u ? p17 : p;
+              p = lane == 19u ? p19 : p;
+              p = lane == 21u ? p21 : p;                   // lanes 18 and 20 (SSE) need no squash
             } else if (SP::nmix >= 1) {
               int term = __mul24(mw[0] >> 8, p);         // lanes that do not feed the mixer hold weight 0
               term += dpp_shr(term, 1); term += dpp_shr(term, 2); term += dpp_shr(term, 4);
@@ -520,6 +580,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
               const int pmx = med3i(term >> 8, -2048, 2047);
               if (lane == SP::mix_lane[0]) p = pmx;
             }
+            C2_STAMP(1);
             // ---- (d) decode
             const int sqp = (int)*(lds_u16_p)((uint32_t)(uintptr_t)lds_squash + (uint32_t)(p + 2048) * 2u);
             const uint32_t prb = rdlane((uint32_t)sqp, SP::final_lane);
@@ -530,6 +591,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
             if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane) && !err) err = bad ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF; }
             const uint32_t y = uni(j & 1);
             const int ey = y ? 32767 : 0;
+            C2_STAMP(2);
             // ---- (e) update (Predictor.cs:363-461)
             const int e = ey - sqp;
             // bit history of this node: next(state, y) -> row byte
@@ -555,7 +617,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
               auto sse_train = [&](uint32_t pn, int dtv) __attribute__((always_inline)) -> uint32_t {                      // Predictor.train, :1031-1036 form
                 const uint32_t count = pn & 0x3ffu;
                 const int error = ey - (int)(pn >> 17);
-                return pn + (((uint32_t)error * (uint32_t)dtv) & 0xFFFFFC00u) + (count < C2Max::sse_limit);
+                return pn + (((uint32_t)error * uni((uint32_t)dtv)) & 0xFFFFFC00u) + (count < C2Max::sse_limit);
               };
               w17 = mix2_train(w17, C2Max::rate17, 17, p15, p16);
               const uint32_t n18 = sse_train(sel18, dtv18);
@@ -577,6 +639,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
             const uint32_t nA = l_isse ? (uint32_t)nw0 : ncm, nB = l_isse ? (uint32_t)nw1 : (uint32_t)npst;
             *(lds_u2_p)ea = v2u{nA, nB};
             *(lds_u8_p)(wrow + (hm & wrow_mask)) = (uint8_t)nsb;
+            C2_STAMP(3);
             // ---- (f) bookkeeping (Predictor.cs:463-474) and hand-over to the next bit
             c8 = c8 * 2u + y;
             if (pre_mx) {
@@ -596,20 +659,32 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
               eB = same ? nB : (y ? e1.y : e0.y);
               ea = nea;
             } else if (bit == 3) {
-              // ---- second nibble (Predictor.cs:267-270: c8 & 0xf0 == 16): new rows
+              // ---- second nibble (Predictor.cs:267-270: c8 & 0xf0 == 16): new rows, requested two bits ago
               v4u old; uint32_t old_off; bool old_valid;
               row_evict(old, old_off, old_valid);
-              Probe pr;
-              rows_issue(c8, pr);
-              rows_finish(pr, old, old_off, old_valid);
+              switch (c8 & 3u) {                         // wave-uniform: four copies of the selection code, no data selects
+                case 0: rows_finish(spec[0], old, old_off, old_valid); break;
+                case 1: rows_finish(spec[1], old, old_off, old_valid); break;
+                case 2: rows_finish(spec[2], old, old_off, old_valid); break;
+                default: rows_finish(spec[3], old, old_off, old_valid); break;
+              }
               hm = 1;
               l0_direct();
+              C2_STAMP(4);
+            }
+            if (bit == 1) {
+              // Two bits of the first nibble are known: the second nibble's context is one of c8*4 .. c8*4+3.  The hash
+              // rows of all four are requested now, so that the HBM round trip runs under bits 2 and 3 (a candidate
+              // that coincides with the row still held in LDS is patched from it when the nibble ends: rows_finish).
+#pragma unroll
+              for (uint32_t k = 0; k < 4; ++k) rows_issue(c8 * 4u + k, spec[k]);
             }
           }
           if (UNLIKELY(err | bad)) { status = err ? -(int)err : ZH_E_CORRUPT; break; }
           c = (int)(c8 - 256);
 
           // ---- byte boundary: MATCH (Predictor.cs:391-410), HCOMP, h[], rows of the next byte
+          if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
           {
             uint32_t cmv = 0;
             if (l_match) {                               // still with the h[i] of the byte just coded (update0 runs before z.run)
@@ -621,14 +696,15 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
             }
             int rc;
             switch (hnative) {
-              case ZH_NATIVE_HCOMP_MIN: rc = zh_native_hcomp_min(ha, hb, hc, hd, hf, (uint32_t)c, lds_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
-              case ZH_NATIVE_HCOMP_MID: rc = zh_native_hcomp_mid(ha, hb, hc, hd, hf, (uint32_t)c, lds_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
-              case ZH_NATIVE_HCOMP_MAX: rc = zh_native_hcomp_max(ha, hb, hc, hd, hf, (uint32_t)c, lds_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
+              case ZH_NATIVE_HCOMP_MIN: rc = zh_native_hcomp_min(ha, hb, hc, hd, hf, (uint32_t)c, reg_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
+              case ZH_NATIVE_HCOMP_MID: rc = zh_native_hcomp_mid(ha, hb, hc, hd, hf, (uint32_t)c, reg_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
+              case ZH_NATIVE_HCOMP_MAX: rc = zh_native_hcomp_max(ha, hb, hc, hd, hf, (uint32_t)c, reg_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
               default: rc = vm_run(hz, (uint32_t)c, nullptr, L.budget); break;
             }
             rc = (int)uni((uint32_t)rc);
             if (rc) { status = rc; break; }
             hv = lds_h[lane & hmask];
+            C2_STAMP(5);
             v4u old; uint32_t old_off; bool old_valid;
             row_evict(old, old_off, old_valid);
             Probe pr;
@@ -652,10 +728,13 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
                   need = (m_ptr & ht_mask) != 0;
                 } else m_len += m_len < 255;
               }
-              if (__ballot(need != 0)) {                 // verify the candidate with the whole wave (Predictor.cs:403-405)
+              uint32_t mb_new = 0;
+              const bool verify = __ballot(need != 0) != 0;
+              if (verify) {                              // verify the candidate with the whole wave (Predictor.cs:403-405)
                 const uint32_t ml = (uint32_t)SP::match_lane;
                 const uint32_t lim = rdlane(m_limit, ml), off = rdlane(m_ptr, ml), msk = rdlane(ht_mask, ml);
                 const uint8_t *hp = slot_mem + rdlane(hto, ml);
+                mb_new = hp[(lim - off) & msk];          // the byte the candidate predicts: same round trip as the comparison
                 uint32_t len = 0;
                 for (uint32_t base = 0; base < 256; base += 64) {
                   const uint32_t t = base + lane;
@@ -666,13 +745,17 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
                 }
                 if (l_match) m_len = len > 255 ? 255 : len;
               }
-              if (l_match) m_byte = (slot_mem + hto)[(m_limit - m_ptr) & ht_mask];
+              if (verify) { if (l_match) m_byte = mb_new; }
+              else if (l_match && m_len) m_byte = (slot_mem + hto)[(m_limit - m_ptr) & ht_mask];
               const int dk = S.dt2k[l_match ? m_len : 0];
               pm0 = S.stretch[dk & 32767];
               pm1 = S.stretch[(-dk) & 32767];
               if (!l_match || m_len == 0) { pm0 = 0; pm1 = 0; }
             }
+            C2_STAMP(6);
             rows_finish(pr, old, old_off, old_valid);
+            asm volatile("" ::: "memory");
+            C2_STAMP(7);
           }
         }
 
@@ -725,24 +808,29 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
         L.results[si] = res;
       }
     }
+    if (PROF && lane == 0 && L.debug)
+      for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
     __syncthreads();
   }
 }
 
 }  // namespace
 
-#define ZH_CHAIN2_KERNEL(name, spec)                                                   \
+#define ZH_CHAIN2_KERNEL(name, spec, prof)                                             \
   extern "C" __global__ __launch_bounds__(64) void name(ZhLaunch L) {                  \
     __shared__ C2Lds S;                                                                \
-    decode_chain2_body<spec>(L, S);                                                    \
+    decode_chain2_body<spec, prof>(L, S);                                              \
   }
-ZH_CHAIN2_KERNEL(zh_decode_c2_min, C2Min)
-ZH_CHAIN2_KERNEL(zh_decode_c2_mid, C2Mid)
-ZH_CHAIN2_KERNEL(zh_decode_c2_max, C2Max)
+ZH_CHAIN2_KERNEL(zh_decode_c2_min, C2Min, false)
+ZH_CHAIN2_KERNEL(zh_decode_c2_mid, C2Mid, false)
+ZH_CHAIN2_KERNEL(zh_decode_c2_max, C2Max, false)
+ZH_CHAIN2_KERNEL(zh_decode_c2_mid_prof, C2Mid, true)
+ZH_CHAIN2_KERNEL(zh_decode_c2_max_prof, C2Max, true)
 
 // spec: 1 min, 2 mid, 3 max (zh_chain_spec.h ids).  Returns hipErrorInvalidValue for a spec this file has no kernel for.
-extern "C" hipError_t zh_launch_chain2(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec) {
+extern "C" hipError_t zh_launch_chain2(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof) {
   void (*k)(ZhLaunch) = spec == 1 ? zh_decode_c2_min : spec == 2 ? zh_decode_c2_mid : spec == 3 ? zh_decode_c2_max : nullptr;
+  if (prof && spec >= 2) k = spec == 2 ? zh_decode_c2_mid_prof : zh_decode_c2_max_prof;
   if (!k) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, stream, *L);
   return hipGetLastError();

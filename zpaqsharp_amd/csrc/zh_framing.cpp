@@ -64,7 +64,8 @@ namespace {
 
 struct Cur {
   const uint8_t *p; size_t n, pos;
-  int get() { return pos < n ? p[pos++] : -1; }
+  bool eof_hit = false;                   // a get() ran into the end of the buffer
+  int get() { if (pos < n) return p[pos++]; eof_hit = true; return -1; }
 };
 
 // ZPAQL.memory(), ZPAQL.cs:58-81 (header_len = hsize + 300 as allocated by ZPAQL.read).
@@ -142,11 +143,41 @@ uint64_t parse_size(const uint8_t *p, size_t n) {
 
 }  // namespace
 
-int scan_stream(const uint8_t *in, size_t n, ScanOut &out, zpaqhip_err *err) {
+// On an error the blocks (and only their segments) parsed before the damaged one are kept in `out`, so that a
+// caller can deliver them first, as the reference's Decompresser would (it only fails on reaching the damage).
+// out.resume_off = where an incremental caller continues once more bytes have arrived; out.hit_eof = the failing
+// block ran into the end of the buffer (more input may complete it).
+static int scan_blocks(Cur &c, const uint8_t *in, ScanOut &out, zpaqhip_err *err, const ScanLimit &lim);
+
+int scan_stream(const uint8_t *in, size_t n, ScanOut &out, zpaqhip_err *err, const ScanLimit &lim) {
   Cur c{in, n, 0};
   out.blocks.clear();
   out.segs.clear();
+  out.resume_off = 0;
+  out.hit_eof = false;
+  out.stopped = false;
+  const int rc = scan_blocks(c, in, out, err, lim);
+  if (out.stopped) { out.resume_off = (size_t)out.blocks.back().end_off; return ZPAQHIP_OK; }
+  const size_t good_end = out.blocks.empty() ? 0 : (size_t)out.blocks.back().end_off;
+  if (rc) {
+    if (!out.blocks.empty()) out.segs.resize(out.blocks.back().first_seg + out.blocks.back().n_seg);
+    else out.segs.clear();
+    out.hit_eof = c.eof_hit;
+    out.resume_off = good_end;           // the damaged / unfinished block is scanned again from its tag
+  } else {
+    // no further tag: only the last 15 bytes can still be the beginning of one
+    out.resume_off = std::max(good_end, n > 15 ? n - 15 : (size_t)0);
+  }
+  return rc;
+}
+
+static int scan_blocks(Cur &c, const uint8_t *in, ScanOut &out, zpaqhip_err *err, const ScanLimit &lim) {
   for (;;) {
+    if (!out.blocks.empty() &&
+        (out.blocks.size() >= lim.max_blocks || (out.blocks.size() >= lim.min_blocks && out.blocks.back().end_off >= lim.min_bytes))) {
+      out.stopped = true;                                // a batch is complete: the caller continues from resume_off
+      return ZPAQHIP_OK;
+    }
     // ---- findBlock: Decompresser.cs:34-45
     uint32_t h1 = 0x3D49B113, h2 = 0x29EB7F93, h3 = 0x2614BE13, h4 = 0x3828EB13;
     int ch;
@@ -215,8 +246,22 @@ int scan_stream(const uint8_t *in, size_t n, ScanOut &out, zpaqhip_err *err) {
           if (v < 0) break;
           curr = (uint32_t)v;
         }
-        if (v >= 0)
-          while (curr && (v = c.get()) >= 0) curr = curr << 8 | (uint32_t)v;
+        if (v >= 0) {
+          // `while (curr && (v = get()) >= 0) curr = curr << 8 | v`: stops behind the first four consecutive zero
+          // bytes after the non-zero byte just read.  Searched with memchr (coded data is ~1/256 zero bytes).
+          const uint8_t *q = c.p + c.pos, *end = c.p + c.n;
+          const uint8_t *hit = nullptr;
+          while (q < end) {
+            const uint8_t *z = (const uint8_t *)memchr(q, 0, (size_t)(end - q));
+            if (!z) break;
+            if (end - z >= 4 && z[1] == 0 && z[2] == 0 && z[3] == 0) { hit = z; break; }
+            q = z + 1;
+            while (q < end && *q == 0) ++q;               // a run shorter than four: skip it whole
+            if (q - z >= 4) { hit = z; break; }          // (cannot happen: kept for clarity of the invariant)
+          }
+          if (hit) c.pos = (size_t)(hit - c.p) + 4;
+          else { c.pos = c.n; c.eof_hit = true; }
+        }
         while ((nx = c.get()) == 0) {}
       } else {
         // unmodelled store path (Decoder.cs:84-96): [len32 big-endian, bytes]* , len 0 ends
@@ -384,6 +429,8 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
     const uint32_t native = zh_native_lookup(hdr + cp, m.hcomp_len);     // native HCOMP id or 0
     // zh_chain2.hip's max code relies on what the built-in HCOMP leaves in h[17..21] (zeros, and an even h[20])
     if (spec == 3 && native != ZH_NATIVE_HCOMP_MAX) spec = 0;
+    // ... and it keeps H in 256 LDS words and M in one or two vector registers (256 / 512 bytes)
+    if (spec && (m.hh > 8 || m.hm > (spec == 3 ? 9u : 8u))) spec = 0;
     m.kind += spec;
     m.kind |= native << 8;
   }

@@ -20,8 +20,16 @@ bool host_tables_ok();
 struct ScanOut {
   std::vector<zpaqhip_block> blocks;
   std::vector<zpaqhip_segment> segs;
+  size_t resume_off = 0;                  // see scan_stream
+  bool hit_eof = false;
+  bool stopped = false;                   // the scan ended on its ScanLimit, not at the end of the buffer
 };
-int scan_stream(const uint8_t *in, size_t n, ScanOut &out, zpaqhip_err *err);
+// Stop after a block once `max_blocks` are found, or `min_blocks` are found and they span `min_bytes` (batching of the
+// streaming forms).  The default never stops early.
+struct ScanLimit {
+  size_t min_blocks = SIZE_MAX, min_bytes = 0, max_blocks = SIZE_MAX;
+};
+int scan_stream(const uint8_t *in, size_t n, ScanOut &out, zpaqhip_err *err, const ScanLimit &lim = ScanLimit());
 // Parses a stream-form header (hsize[2] hh hm ph pm n COMP 0 HCOMP 0) into a
 // ZhModel + padded code window.  Mirrors ZPAQL.read (ZPAQL.cs:112-156) and the
 // limit checks of Predictor.init (Predictor.cs:94-167).
