@@ -116,9 +116,12 @@ typedef struct zpaqhip_opts {
   uint32_t verify_sha1;       /* 1: check stored SHA-1 of every segment (Decompresser.cs:183-191 contract); hashed on the GPU */
   uint32_t max_concurrent;    /* blocks in flight per launch; 0 = auto (memory-bound) */
   uint32_t kernel;            /* 0 auto; 1 force the generic (one-lane) kernel; 3 prefer the lane-per-component kernel;
-                                 4 lane-per-component without model specialisation */
+                                 4 lane-per-component without model specialisation; 5 the run-time-level form of the
+                                 lane-per-component kernel also for the built-in min/mid/max models (cross-check) */
   uint64_t zpaql_budget;      /* max ZPAQL instructions per run() call; 0 = default (1<<32) */
-  uint64_t reserved[4];
+  uint64_t batch_blocks;      /* whole-stream forms: blocks per pipeline batch; 0 = default (at least 256 blocks and 32 MiB
+                                 of coded bytes per batch, so that every CU has a block) */
+  uint64_t reserved[3];
 } zpaqhip_opts;
 
 /* Timing / accounting of the last decode call on a context (the reference's
@@ -186,7 +189,8 @@ int zpaqhip_decompress_cb(zpaqhip_ctx *ctx, zpaqhip_read_fn read_fn, zpaqhip_wri
 /* ---- explicit block-table form, device-resident buffers ------------------
  * Replaces the per-block inner loop Decompresser.decompress(-1)
  * (Decompresser.cs:121-153) for a set of blocks.  `d_in` is the whole stream in
- * device memory; `ids[0..n_ids)` selects the blocks this GPU decodes (NULL =
+ * device memory; it must be 4-byte aligned and readable up to in_len rounded up to
+ * a multiple of 4 (the kernels fetch the coded bytes as aligned dwords); `ids[0..n_ids)` selects the blocks this GPU decodes (NULL =
  * all, in table order) — the multi-GPU scheduler gives each rank its shard.
  * Block ids[i] writes its plaintext (all segments, concatenated) at
  * d_out + out_off[i], at most out_cap[i] bytes; bytes past the capacity are

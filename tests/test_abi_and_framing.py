@@ -123,3 +123,31 @@ def test_scan_errors_match_the_oracle(mutate, code, msg):
 def test_scan_of_empty_and_tagless_input():
     assert z.scan(b"").n_blocks == 0
     assert z.scan(b"no zpaq here" * 100).n_blocks == 0
+
+
+def test_scan_hands_back_the_blocks_before_framing_damage():
+    """A damaged or truncated block does not hide the blocks before it: zpaqhip_scan returns their tables together
+    with the error (the reference's Decompresser delivers them and fails only on reaching the damage)."""
+    good1, good2 = util.block("l1", util.text(3000, 1)), util.block("mid", util.text(500, 3))
+    bad = bytearray(util.block("l1", util.text(2000, 2)))
+    g = z.scan(bytes(bad)).segments[0]
+    bad[g.data_off - 1] = 7                                  # the reserved byte after the comment (Decompresser.cs:107)
+    s = good1 + bytes(bad) + good2
+    with pytest.raises(z.ZpaqError, match="missing reserved byte"):
+        z.scan(s)
+    sc, err = z.scan(s, partial=True)
+    assert sc.n_blocks == 1 and sc.n_segments == 1 and err.code == -14 and err.block == 1
+    assert sc.blocks[0].end_off == len(good1)
+    sc, err = z.scan(good1 + good2[:len(good2) // 2], partial=True)     # input ends inside the second block
+    assert sc.n_blocks == 1 and err is not None
+    sc, err = z.scan(good1 + good2, partial=True)
+    assert sc.n_blocks == 2 and err is None
+    # the oracle walks the same stream the same way: first block fine, error at the second
+    d = oracle.Decompresser(s)
+    assert d.find_block() is not None and d.find_filename() is not None
+    d.read_comment()
+    assert d.decompress()[0] == util.text(3000, 1)
+    d.read_segment_end()
+    assert d.find_filename() is None and d.find_block() is not None and d.find_filename() is not None
+    with pytest.raises(oracle.OracleError, match="missing reserved byte"):
+        d.read_comment()

@@ -244,3 +244,110 @@ def test_two_ranks_on_one_gpu_run_the_sharded_hip_decode(tmp_path):
     line = json.loads(outs[0][0].decode().strip().splitlines()[-1])
     assert line["bit_exact"] is True and line["n_gpus"] == 2 and line["value"] > 0
     assert sorted(line["config"]["shard_blocks"]) == [5, 5] and line["config"]["kernel_kind"] == 3
+
+
+# ---------------------------------------------------------------------------------------
+# whole-stream pipeline (batches, Reader/Writer streaming, unknown sizes, damage behind good blocks)
+# ---------------------------------------------------------------------------------------
+def _mixed_stream(n_blocks=23, seed=5):
+    rng = np.random.default_rng(seed)
+    parts, plain = [], []
+    for i in range(n_blocks):
+        model = ("l1", "min", "mid")[i % 3]
+        d = util.text(int(rng.integers(0, 9000)), seed=100 + i)
+        kw = {}
+        if i % 4 == 1:
+            kw["comment"] = b"jDC\x01"                      # journaling-style comment: no size
+        if i % 4 == 2:
+            kw["comment"] = b"123456789012 not a size"      # digits that are not the size (a date, say)
+        parts.append(util.block(model, d, **kw))
+        plain.append(d)
+    return b"".join(parts), b"".join(plain)
+
+
+def test_pipeline_batches_and_unknown_sizes_cost_one_decode(ctx):
+    """Several batches through the H2D / kernel / D2H pipeline; blocks without (or with a wrong) size hint are decoded
+    once into provisional slots (zpaqhip_stats.launches counts the kernel launches of the call)."""
+    s, want = _mixed_stream()
+    for bb in (0, 4, 7):
+        got = ctx.decompress(s, out_cap=len(want), verify_sha1=True, batch_blocks=bb).tobytes()
+        assert got == want, bb
+        st = ctx.stats()
+        nbatch = 1 if bb == 0 else -(-23 // bb)
+        assert st.launches <= 3 * nbatch, (bb, st.launches)           # <= one launch per kernel family and batch: no second pass
+        assert st.out_bytes == len(want)
+    # a block far larger than its provisional slot (16 x coded size) is the one case that is decoded twice
+    big = b"\0" * 3_000_000
+    s2 = util.block("l1", big, comment=b"no size")
+    assert len(s2) * 16 < len(big)
+    assert ctx.decompress(s2, out_cap=len(big), verify_sha1=True).tobytes() == big
+    assert ctx.stats().launches == 2
+    # a hostile size hint (12-digit "size") neither allocates terabytes nor fails
+    s3 = util.block("l1", b"abc" * 1000, comment=b"999999999999")
+    assert ctx.decompress(s3, out_cap=3000, verify_sha1=True).tobytes() == b"abc" * 1000
+
+
+def test_reader_writer_streaming_in_batches(ctx):
+    """zpaqhip_decompress_cb reads incrementally (short reads), scans batch by batch and writes in stream order."""
+    s, want = _mixed_stream(n_blocks=31, seed=9)
+    for bb in (0, 5):
+        pos, out, reads = [0], bytearray(), [0]
+
+        def rd(n):
+            k = min(n, 1 + (reads[0] * 7919) % 5000)         # ragged short reads
+            reads[0] += 1
+            chunk = s[pos[0]:pos[0] + k]
+            pos[0] += len(chunk)
+            return chunk
+
+        ctx.decompress_cb(rd, out.extend, verify_sha1=True, batch_blocks=bb)
+        assert bytes(out) == want, bb
+    # trailing garbage and leading junk are skipped like findBlock does
+    pos, out = [0], bytearray()
+    s2 = b"junk" * 10 + s + b"tail" * 5
+
+    def rd2(n):
+        chunk = s2[pos[0]:pos[0] + min(n, 4096)]
+        pos[0] += len(chunk)
+        return chunk
+
+    ctx.decompress_cb(rd2, out.extend, batch_blocks=3)
+    assert bytes(out) == want
+
+
+def test_good_blocks_before_damage_are_delivered(ctx):
+    """Framing damage or a corrupt segment in block k: blocks 0..k-1 arrive, then the error is raised — for the buffer
+    form, the Reader/Writer form and the Decompresser mirror (the reference fails only on reaching the damage)."""
+    from zpaqsharp_amd import decompresser as D
+    a, b, c = util.text(5000, 1), util.text(3000, 2), util.text(700, 3)
+    good1, good3 = util.block("l1", a), util.block("mid", c)
+    bad = bytearray(util.block("min", b))
+    g = z.scan(bytes(bad)).segments[0]
+    framing = bytearray(bad); framing[g.data_off - 1] = 9          # reserved byte
+    coded = bytearray(bad); coded[g.data_off + 40] ^= 0x20         # inside the coded data
+    for dmg, msg in ((bytes(framing), "missing reserved byte"), (bytes(coded), None)):
+        s = good1 + dmg + good3
+        out = bytearray()
+        pos = [0]
+
+        def rd(n):
+            chunk = s[pos[0]:pos[0] + min(n, 3000)]
+            pos[0] += len(chunk)
+            return chunk
+
+        with pytest.raises(z.ZpaqError) as e:
+            ctx.decompress_cb(rd, out.extend, batch_blocks=1 if msg else 0)
+        if msg:
+            assert msg in str(e.value)
+        assert bytes(out[:len(a)]) == a and len(out) < len(a) + len(b) + len(c)
+        # the mirror: first block complete, then the error where the reference raises it
+        d = D.Decompresser(ctx)
+        d.setInput(D.BytesReader(s))
+        w = D.BytesWriter(); d.setOutput(w)
+        assert d.findBlock() and d.findFilename()
+        d.readComment(); assert d.decompress() is False; d.readSegmentEnd()
+        assert bytes(w.buf) == a and not d.findFilename()
+        with pytest.raises(z.ZpaqError):
+            if d.findBlock() and d.findFilename():
+                d.readComment()
+                d.decompress()

@@ -1,0 +1,71 @@
+"""The reference's method strings (LibZPAQ.makeConfig, LibZPAQ.cs:388-1044): generated configs, the LZ77 / BWT / E8E9
+pre-processors (LZBuffer.cs formats) and their PCOMP programs, checked on the oracle (CPU) and on the GPU."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle
+import zpaqsharp_amd as z
+from tests import util
+from zpaqsharp_amd import methods, zpaql
+
+METHODS = [
+    "x0,1,4,0,3,16",                 # level 1: lazy2, bit-packed LZ77, no model (n = 0: stored)      LibZPAQ.cs:427-572
+    "x0,5,4,0,3,16",                 # ... + E8E9 at end of segment
+    "x6,1,4,0,3,24",                 # ... 64 MiB block: low offset bits travel separately (rb = 2)
+    "x0,2,12,0,7,16,1c0,0,511i2",    # level 2: lzpre, byte-aligned LZ77 + ICM/ISSE over the parse state  :575-639
+    "x0,6,5,0,3,16c0,0,511",         # ... + E8E9, CM
+    "x0,3ci1",                       # level 3: bwtrle, inverse BWT at end of segment                 :642-795
+    "x0,7ci1",                       # ... + E8E9
+    "x5,3ci1",                       # ... blocks > 16 MiB: the slower list traversal
+    "x5,7ci1",
+    "x0,4ci1,1,1,1,2am",             # E8E9 alone in front of an ICM-ISSE chain + MATCH + MIX         :802-826
+    "x0,0c0,0,255w1i1c256ci1,1,1,1,1,1,2ac0,2,0,255i1c0,3,0,0,255i1c0,4,0,0,0,255i1mm16ts19t0",   # the level-5 recipe
+]
+
+
+def _data(n=9000):
+    return util.text(n * 2 // 3, 3) + util.x86ish(n // 4, 4) + b"ab" * (n // 24)
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_method_configs_on_the_oracle(method):
+    data = _data()
+    text, args = methods.make_config(method)
+    m = zpaql.assemble(text)
+    pre = methods.preprocess(data, args)
+    if m.pcomp:                                                  # PCOMP inverts the pre-processor
+        assert oracle.run_pcomp(m.pcomp, pre, m.header[4], m.header[5], cap=1 << 20) == data
+    s = methods.compress_block(method, data)
+    assert oracle.decompress(s, cap=1 << 20) == data
+    sc = z.scan(s)
+    assert sc.n_blocks == 1 and sc.blocks[0].usize_hint == len(data) and bytes(sc.segments[0].sha1) == hashlib.sha1(data).digest()
+
+
+def test_preprocessor_formats_on_edge_inputs():
+    for data in (b"", b"a", b"abcd" * 2, bytes(300), bytes(range(256)) * 2):
+        for method in ("x0,1,4,0,3,16", "x0,2,4,0,3,16c0,0,511", "x0,3ci1", "x0,7ci1"):
+            text, args = methods.make_config(method)
+            m = zpaql.assemble(text)
+            pre = methods.preprocess(data, args)
+            assert oracle.run_pcomp(m.pcomp, pre, m.header[4], m.header[5], cap=1 << 16) == data, (method, len(data))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", METHODS)
+def test_method_streams_on_the_gpu(ctx, method):
+    data = _data(30000)
+    s = methods.compress_block(method, data)
+    for kernel in (0, 1):
+        assert ctx.decompress(s, verify_sha1=True, kernel=kernel).tobytes() == data, kernel
+    m, _ = methods.model_of(method)
+    if m.pcomp:
+        assert ctx.block_pcomp(s, 0)[2:] == m.pcomp
+
+
+@pytest.mark.gpu
+def test_method_streams_multi_block(ctx):
+    parts = [(mt, _data(4000 + 700 * i)) for i, mt in enumerate(METHODS[:7])]
+    s = b"".join(methods.compress_block(mt, d) for mt, d in parts)
+    assert ctx.decompress(s, verify_sha1=True).tobytes() == b"".join(d for _, d in parts)

@@ -41,7 +41,8 @@ class SegResult(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("verify_sha1", C.c_uint32), ("max_concurrent", C.c_uint32),
-                ("kernel", C.c_uint32), ("zpaql_budget", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+                ("kernel", C.c_uint32), ("zpaql_budget", C.c_uint64), ("batch_blocks", C.c_uint64),
+                ("reserved", C.c_uint64 * 3)]
 
 
 class Stats(C.Structure):

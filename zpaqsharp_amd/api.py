@@ -60,31 +60,38 @@ class ScanResult:
         return len(self.segments)
 
 
-def scan(stream) -> ScanResult:
+def scan(stream, partial: bool = False):
     """Host-side framing scan (Decompresser.findBlock/findFilename/readComment/
-    readSegmentEnd, Decompresser.cs:29-108,163-194) → block and segment tables."""
+    readSegmentEnd, Decompresser.cs:29-108,163-194) → block and segment tables.
+    partial=True: a framing error does not raise; the blocks parsed before the damage are returned together with
+    the error, (ScanResult, ZpaqError | None) — the reference's Decompresser delivers those blocks too."""
     L = _lib.load()
     a = _as_u8(stream)
     nb, ns, err = C.c_size_t(0), C.c_size_t(0), Err()
     rc = L.zpaqhip_scan(a.ctypes.data, a.size, None, 0, C.byref(nb), None, 0, C.byref(ns), C.byref(err))
-    if rc:
+    if rc and not partial:
         _raise(err, rc)
     blocks = (Block * max(1, nb.value))()
     segs = (Segment * max(1, ns.value))()
     rc = L.zpaqhip_scan(a.ctypes.data, a.size, blocks, nb.value, C.byref(nb), segs, ns.value, C.byref(ns), C.byref(err))
-    if rc:
+    if rc and not partial:
         _raise(err, rc)
-    return ScanResult((Block * nb.value).from_buffer(blocks) if nb.value else (Block * 0)(),
-                      (Segment * ns.value).from_buffer(segs) if ns.value else (Segment * 0)())
+    res = ScanResult((Block * nb.value).from_buffer(blocks) if nb.value else (Block * 0)(),
+                     (Segment * ns.value).from_buffer(segs) if ns.value else (Segment * 0)())
+    if partial:
+        return res, (ZpaqError(rc, err.block, err.segment, err.msg.decode(errors="replace")) if rc else None)
+    return res
 
 
-def make_opts(verify_sha1: bool = False, max_concurrent: int = 0, kernel: int = 0, zpaql_budget: int = 0) -> Opts:
+def make_opts(verify_sha1: bool = False, max_concurrent: int = 0, kernel: int = 0, zpaql_budget: int = 0,
+              batch_blocks: int = 0) -> Opts:
     o = Opts()
     o.struct_size = C.sizeof(Opts)
     o.verify_sha1 = int(verify_sha1)
     o.max_concurrent = max_concurrent
     o.kernel = kernel
     o.zpaql_budget = zpaql_budget
+    o.batch_blocks = batch_blocks
     return o
 
 
@@ -187,6 +194,12 @@ class Context:
                 res = (SegResult * max(1, rcap))()
                 continue
             break
+        # a framing error behind the last good block: the results of the blocks before it are valid; the caller finds
+        # the error in `framing_error` and raises it on reaching that point (as the reference would)
+        self.framing_error = None
+        if rc in (-2, -5, -11, -12, -13, -14, -15) and nr.value <= rcap and n.value <= cap:
+            self.framing_error = ZpaqError(rc, err.block, err.segment, err.msg.decode(errors="replace"))
+            rc = 0
         if rc:
             _raise(err, rc)
         return out[:n.value], res

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <numeric>
 #include <string>
@@ -51,6 +52,12 @@ struct zpaqhip_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   DevBuf tables, arena, models, code, bdesc, sdesc, results, queue, in, out;
+  // whole-stream pipeline (created on first use): copy streams, double-buffered device input / staging / second-pass
+  // buffers, pinned chunks for the Writer callback
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_pin[2] = {nullptr, nullptr}, ev_h0 = nullptr, ev_h1 = nullptr;
+  DevBuf in2[2], out2[2], out_fix[2];
+  uint8_t *pin[2] = {nullptr, nullptr};
   zpaqhip_stats stats{};
   std::vector<uint32_t> raw_pp;           // last decode: per segment pp_state | PCOMP length << 8, as the kernels report it
 };
@@ -126,8 +133,18 @@ int zpaqhip_ctx_create(int device, zpaqhip_ctx **out, zpaqhip_err *err) {
 void zpaqhip_ctx_destroy(zpaqhip_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (DevBuf *b : {&c->tables, &c->arena, &c->models, &c->code, &c->bdesc, &c->sdesc, &c->results, &c->queue, &c->in, &c->out})
+  for (DevBuf *b : {&c->tables, &c->arena, &c->models, &c->code, &c->bdesc, &c->sdesc, &c->results, &c->queue, &c->in, &c->out,
+                    &c->in2[0], &c->in2[1], &c->out2[0], &c->out2[1], &c->out_fix[0], &c->out_fix[1]})
     b->release();
+  for (int i = 0; i < 2; ++i) {
+    if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+    if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
+    if (c->ev_pin[i]) (void)hipEventDestroy(c->ev_pin[i]);
+  }
+  if (c->ev_h0) (void)hipEventDestroy(c->ev_h0);
+  if (c->ev_h1) (void)hipEventDestroy(c->ev_h1);
+  if (c->s_in) (void)hipStreamDestroy(c->s_in);
+  if (c->s_out) (void)hipStreamDestroy(c->s_out);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -144,17 +161,21 @@ int zpaqhip_scan(const uint8_t *in, size_t in_len, zpaqhip_block *blocks, size_t
                  zpaqhip_segment *segs, size_t seg_cap, size_t *n_segs, zpaqhip_err *err) {
   if ((!in && in_len) || !n_blocks || !n_segs) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
   ScanOut so;
-  int rc = scan_stream(in, in_len, so, err);
+  zpaqhip_err e2{};
+  const int rc = scan_stream(in, in_len, so, &e2);
+  // On a framing error the blocks before the damage are still handed back (counts and tables), with the error code:
+  // the reference's Decompresser delivers them too and only fails on reaching the damaged block.
   *n_blocks = so.blocks.size();
   *n_segs = so.segs.size();
-  if (rc) return rc;
   if (so.blocks.size() > block_cap || so.segs.size() > seg_cap) {
-    if (block_cap || seg_cap) set_err(err, ZPAQHIP_E_ARG, -1, -1, "block/segment table too small");
-    return (block_cap || seg_cap) ? ZPAQHIP_E_ARG : ZPAQHIP_OK;
+    if (block_cap || seg_cap) { set_err(err, ZPAQHIP_E_ARG, -1, -1, "block/segment table too small"); return ZPAQHIP_E_ARG; }
+    if (rc && err) *err = e2;
+    return rc;
   }
   if (blocks && !so.blocks.empty()) memcpy(blocks, so.blocks.data(), so.blocks.size() * sizeof(zpaqhip_block));
   if (segs && !so.segs.empty()) memcpy(segs, so.segs.data(), so.segs.size() * sizeof(zpaqhip_segment));
-  return ZPAQHIP_OK;
+  if (rc && err) *err = e2;
+  return rc;
 }
 
 int zpaqhip_read_device_tables(zpaqhip_ctx *c, uint16_t *squash, int16_t *stretch, int32_t *dt, int32_t *dt2k,
@@ -333,7 +354,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     L.queue = (uint32_t *)c->queue.p + 8 * g;           // one work-queue head per launch
     L.n_blocks = (uint32_t)groups[g].size();
     L.budget = opts.zpaql_budget;
-    L.flags = opts.reserved[0] == kPpOnlyMagic ? ZH_LAUNCH_PP_ONLY : 0u;
+    L.flags = opts.reserved[1] == kPpOnlyMagic ? ZH_LAUNCH_PP_ONLY : 0u;
     const bool prof = getenv("ZPAQHIP_PROF") != nullptr;   // diagnostic build with in-kernel stamps
     if (prof) L.debug = (uint64_t *)((uint8_t *)c->queue.p + kQueueBytes);
     if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, slots_of[g], stream));
@@ -435,116 +456,448 @@ extern "C" int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, co
 
 
 // ---------------------------------------------------------------------------
-// Whole-stream forms
+// Whole-stream forms: a three-stage pipeline over batches of whole blocks
+//
+//   source (caller's buffer, or Reader-shaped callback read incrementally)
+//     -> scan a batch (>= 256 blocks when the stream has them)            host
+//     -> H2D of the batch's bytes                                         stream s_in
+//     -> decode kernels (zh_* families)                                   stream c->stream
+//     -> D2H of the plaintext, block by block, into stream order          stream s_out
+//   sink (caller's buffer, or Writer-shaped callback fed from pinned chunks)
+//
+// While the kernels of batch k run, the host drains the output of batch k-1 and reads / scans / uploads batch k+1
+// (double-buffered device input and staging buffers).  Blocks whose plaintext size is unknown (no decimal size in the
+// segment comment, LICENSE:57-58) get a provisional staging slot and are decoded ONCE; only a block that overflows its
+// slot is decoded a second time, alone, with the exact size it reported.
 // ---------------------------------------------------------------------------
 namespace {
 
-// Decodes a host-resident stream; the plaintext ends up in ctx->out (device),
-// laid out in stream order.  Returns total plaintext length in *total.
 bool data_error(int rc) {                 // per-segment outcomes, as opposed to failures of the call itself
   return rc < 0 && rc != ZPAQHIP_E_HIP && rc != ZPAQHIP_E_ARG && rc != ZPAQHIP_E_DEVICE_MEM && rc != ZPAQHIP_E_NO_DEVICE &&
-         rc != ZPAQHIP_E_HEADER && rc != ZPAQHIP_E_COMPONENT && rc != ZPAQHIP_E_HM_TOO_BIG;
+         rc != ZPAQHIP_E_HEADER && rc != ZPAQHIP_E_COMPONENT && rc != ZPAQHIP_E_HM_TOO_BIG && rc != ZPAQHIP_E_CALLBACK;
 }
 
-int decode_stream_to_device(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, const zpaqhip_opts &opts, ScanOut &so,
-                            std::vector<zpaqhip_seg_result> &res, uint64_t *total, zpaqhip_err *err,
-                            bool tolerate = false) {
-  int rc = scan_stream(in, in_len, so, err);
-  if (rc) return rc;
-  *total = 0;
-  res.assign(so.segs.size(), zpaqhip_seg_result{});
-  if (so.blocks.empty()) return ZPAQHIP_OK;
-  HIPCHK(hipSetDevice(c->device));
-  HIPCHK(c->in.reserve(in_len + 16));
-  hipEvent_t e0 = c->ev0, e1 = c->ev1;
-  HIPCHK(hipEventRecord(e0, c->stream));
-  HIPCHK(hipMemcpyAsync(c->in.p, in, in_len, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipEventRecord(e1, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  float h2d = 0;
-  HIPCHK(hipEventElapsedTime(&h2d, e0, e1));
+struct Source {
+  const uint8_t *mem = nullptr;           // memory form
+  size_t mem_len = 0, mem_pos = 0;
+  zpaqhip_read_fn rd = nullptr;           // callback form (Reader.read, Reader.cs:14-25)
+  void *user = nullptr;
+  std::vector<uint8_t> buf;               // bytes read and not yet handed to a batch
+  bool eof = false;
+  uint64_t consumed = 0;                  // stream offset of the next unconsumed byte
+};
 
-  const size_t nb = so.blocks.size();
-  std::vector<uint64_t> off(nb), cap(nb);
-  // pass 1: place by the decimal sizes in the segment comments (LibZPAQ.compress
-  // writes them, LICENSE:57-58); blocks without a size are decoded in count-only mode.
-  uint64_t pos = 0;
-  bool exact_possible = true;
-  for (size_t b = 0; b < nb; ++b) {
-    uint64_t hint = so.blocks[b].usize_hint;
-    if (hint == UINT64_MAX || hint > (1ull << 40)) { hint = 0; exact_possible = false; }
-    off[b] = pos; cap[b] = hint; pos += hint;
-  }
-  HIPCHK(c->out.reserve((size_t)pos + 16));
-  rc = zpaqhip_decode_blocks_device(c, c->in.p, in, in_len, so.blocks.data(), nb, so.segs.data(), so.segs.size(), nullptr, 0,
-                                    c->out.p, off.data(), cap.data(), res.data(), &opts, c->stream, err);
-  zpaqhip_stats st1 = c->stats;
-  if (rc && !(tolerate && data_error(rc))) return rc;
-  // did every block land exactly where the final layout wants it?
-  std::vector<uint64_t> real(nb, 0);
-  bool ok = exact_possible;
-  uint64_t pos2 = 0;
-  for (size_t b = 0; b < nb; ++b) {
-    for (uint32_t s = 0; s < so.blocks[b].n_seg; ++s) real[b] += res[so.blocks[b].first_seg + s].out_len;
-    if (real[b] != cap[b] || pos2 != off[b]) ok = false;
-    pos2 += real[b];
-  }
-  *total = pos2;
-  if (!ok) {
-    // pass 2: sizes are now known exactly; decode again into the final layout.
-    pos = 0;
-    for (size_t b = 0; b < nb; ++b) { off[b] = pos; cap[b] = real[b]; pos += real[b]; }
-    HIPCHK(c->out.reserve((size_t)pos + 16));
-    rc = zpaqhip_decode_blocks_device(c, c->in.p, in, in_len, so.blocks.data(), nb, so.segs.data(), so.segs.size(), nullptr,
-                                      0, c->out.p, off.data(), cap.data(), res.data(), &opts, c->stream, err);
-    c->stats.kernel_ms += st1.kernel_ms;
-    c->stats.launches += st1.launches;
-    if (rc && !(tolerate && data_error(rc))) return rc;
-  }
-  c->stats.h2d_ms = h2d;
-  return ZPAQHIP_OK;
-}
+struct Batch {
+  std::vector<uint8_t> own;               // callback form: the batch's bytes (moved out of Source::buf)
+  const uint8_t *h = nullptr;             // host bytes [0, len): whole blocks; tables in `so` are relative to h
+  size_t len = 0;
+  uint64_t stream_off = 0;
+  ScanOut so;
+  size_t blk0 = 0, seg0 = 0;              // global index of the first block / segment
+  std::vector<uint64_t> off, cap, real;   // staging offset / capacity / plaintext length per block
+  std::vector<zpaqhip_seg_result> res;    // per segment; out_off relative to the staging buffer
+  int slot = 0;
+  int rc_after = 0;                       // framing error that follows the last block of this batch ...
+  zpaqhip_err err_after{};                // ... reported once everything before it has been delivered
+  bool last = false;
+};
 
-// SHA-1 of every decoded segment that stores one, computed ON THE DEVICE over ctx->out (zh_sha1_dev.hip) while the
-// plaintext is still there; bad[s] = 1 where the digest differs from the stored one (Decompresser.cs:183-191).
-int sha1_mismatches(zpaqhip_ctx *c, const ScanOut &so, const std::vector<zpaqhip_seg_result> &res, std::vector<int> &bad,
-                    zpaqhip_err *err) {
-  const size_t ns = so.segs.size();
-  bad.assign(ns, 0);
-  std::vector<uint64_t> tab;
-  std::vector<uint32_t> which;
-  for (size_t s = 0; s < ns; ++s) {
-    if (!(so.segs[s].flags & 1) || res[s].status != ZPAQHIP_OK) continue;
-    tab.push_back(res[s].out_off);
-    tab.push_back(res[s].out_len);
-    which.push_back((uint32_t)s);
+struct Batch;
+int sha1_mismatches(zpaqhip_ctx *c, const Batch &bt, std::vector<int> &bad, zpaqhip_err *err);
+
+struct Sinkk {
+  uint8_t *mem = nullptr; size_t cap = 0; // memory form
+  zpaqhip_write_fn wr = nullptr;          // callback form (Writer.write, Writer.cs:19-24)
+  void *user = nullptr;
+  uint64_t total = 0;                     // plaintext bytes so far (counted past `cap` too)
+};
+
+constexpr size_t kBatchMinBlocks = 256, kBatchMinBytes = 32u << 20, kBatchMaxBlocks = 4096;
+constexpr size_t kReadChunk = 4u << 20, kPinChunk = 32u << 20;
+
+// Next batch of whole blocks, or batch.so.blocks.empty() at the end of the stream.  Returns a call-level error only.
+int next_batch(Source &src, Batch &bt, size_t blk0, size_t seg0, size_t batch_blocks, zpaqhip_err *err) {
+  ScanLimit lim;
+  lim.min_blocks = kBatchMinBlocks; lim.min_bytes = kBatchMinBytes; lim.max_blocks = kBatchMaxBlocks;
+  if (batch_blocks) { lim.min_blocks = lim.max_blocks = batch_blocks; lim.min_bytes = 0; }   // zpaqhip_opts.batch_blocks
+  bt = Batch();
+  bt.blk0 = blk0; bt.seg0 = seg0;
+  zpaqhip_err e2{};
+  if (src.mem || !src.rd) {
+    const uint8_t *w = src.mem + src.mem_pos;
+    const size_t wl = src.mem_len - src.mem_pos;
+    int rc = scan_stream(w, wl, bt.so, &e2, lim);
+    bt.h = w; bt.stream_off = src.mem_pos;
+    bt.len = bt.so.blocks.empty() ? 0 : (size_t)bt.so.blocks.back().end_off;
+    if (rc) { bt.rc_after = rc; bt.err_after = e2; bt.last = true; src.mem_pos = src.mem_len; }
+    else if (bt.so.stopped) src.mem_pos += bt.so.resume_off;
+    else { bt.last = true; src.mem_pos = src.mem_len; }
+    return ZPAQHIP_OK;
   }
-  if (which.empty()) return ZPAQHIP_OK;
-  const size_t tab_bytes = tab.size() * 8, dig_bytes = which.size() * 20;
-  HIPCHK(c->sdesc.reserve(tab_bytes + dig_bytes + 64));          // the descriptors of the finished decode are not needed any more
-  uint8_t *d_tab = (uint8_t *)c->sdesc.p, *d_dig = d_tab + ((tab_bytes + 15) & ~(size_t)15);
-  HIPCHK(hipMemcpyAsync(d_tab, tab.data(), tab_bytes, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(zh_launch_sha1((const uint8_t *)c->out.p, (const uint64_t *)d_tab, (uint32_t)which.size(), (uint32_t *)d_dig, c->stream));
-  std::vector<uint32_t> dig(which.size() * 5);
-  HIPCHK(hipMemcpyAsync(dig.data(), d_dig, dig_bytes, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  for (size_t k = 0; k < which.size(); ++k) {
-    uint8_t d[20];
-    for (int i = 0; i < 5; ++i) {
-      const uint32_t v = dig[5 * k + i];
-      d[4 * i] = (uint8_t)(v >> 24); d[4 * i + 1] = (uint8_t)(v >> 16); d[4 * i + 2] = (uint8_t)(v >> 8); d[4 * i + 3] = (uint8_t)v;
+  for (;;) {                                            // Reader form: read until a batch is complete or the input ends
+    int rc = scan_stream(src.buf.data(), src.buf.size(), bt.so, &e2, lim);
+    const bool complete = bt.so.stopped || src.eof;
+    if (rc && !(bt.so.hit_eof && !src.eof)) {           // damage that more input cannot repair
+      bt.rc_after = rc; bt.err_after = e2; bt.last = true;
+    } else if (!complete) {
+      const size_t old = src.buf.size();
+      src.buf.resize(old + kReadChunk);
+      int n = src.rd(src.user, src.buf.data() + old, (int)kReadChunk);
+      if (n < 0) { set_err(err, ZPAQHIP_E_CALLBACK, -1, -1); return ZPAQHIP_E_CALLBACK; }
+      src.buf.resize(old + (size_t)n);
+      if (n == 0) src.eof = true;
+      continue;
+    } else if (rc) {                                    // input ended inside a block
+      bt.rc_after = rc; bt.err_after = e2; bt.last = true;
     }
-    bad[which[k]] = memcmp(d, so.segs[which[k]].sha1, 20) != 0;
+    if (!bt.so.stopped) bt.last = true;
+    bt.len = bt.so.blocks.empty() ? 0 : (size_t)bt.so.blocks.back().end_off;
+    bt.stream_off = src.consumed;
+    // hand the batch its bytes; keep the unconsumed tail for the next one
+    const size_t keep_from = bt.last ? src.buf.size() : bt.so.resume_off;
+    bt.own.assign(src.buf.begin(), src.buf.begin() + (ptrdiff_t)bt.len);
+    src.buf.erase(src.buf.begin(), src.buf.begin() + (ptrdiff_t)keep_from);
+    src.consumed += keep_from;
+    bt.h = bt.own.data();
+    return ZPAQHIP_OK;
+  }
+}
+
+void rebase_err(zpaqhip_err *err, const Batch &bt) {
+  if (!err) return;
+  if (err->block >= 0) err->block += (int)bt.blk0;
+  if (err->segment >= 0) err->segment += (int)bt.seg0;
+}
+
+// Staging layout of a batch: the size hint of a block when the stream carries one, else a provisional slot.
+int plan_staging(zpaqhip_ctx *c, Batch &bt, zpaqhip_err *err) {
+  const size_t nb = bt.so.blocks.size();
+  bt.off.assign(nb, 0); bt.cap.assign(nb, 0); bt.real.assign(nb, 0);
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  free_b += c->out2[0].cap + c->out2[1].cap;
+  const uint64_t budget = free_b / 4;                   // per staging buffer; the arena needs the rest
+  uint64_t sum = 0;
+  for (size_t b = 0; b < nb; ++b) {
+    const zpaqhip_block &B = bt.so.blocks[b];
+    uint64_t coded = 0;
+    for (uint32_t i = 0; i < B.n_seg; ++i) coded += bt.so.segs[B.first_seg + i].data_len;
+    uint64_t cap = B.usize_hint;
+    // The hint is untrusted text (a comment that merely starts with digits, or a hostile archive): it only places the
+    // block when it is plausible; anything else gets the provisional slot and, if that overflows, an exact second pass.
+    if (cap == UINT64_MAX || cap > (1ull << 40) || cap > budget)
+      cap = std::min<uint64_t>(std::max<uint64_t>(16 * coded, 64u << 10), 256ull << 20);
+    bt.cap[b] = cap;
+    sum += cap;
+  }
+  if (sum > budget) {                                   // does not fit: count-only for the largest slots until it does
+    std::vector<size_t> order(nb);
+    std::iota(order.begin(), order.end(), (size_t)0);
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b2) { return bt.cap[a] > bt.cap[b2]; });
+    for (size_t k = 0; k < nb && sum > budget; ++k) { sum -= bt.cap[order[k]]; bt.cap[order[k]] = 0; }
+  }
+  uint64_t pos = 0;
+  for (size_t b = 0; b < nb; ++b) { bt.off[b] = pos; pos += bt.cap[b]; }
+  if (c->out2[bt.slot].reserve((size_t)pos + 16) != hipSuccess) {   // not even that: everything count-only, exact second pass
+    (void)hipGetLastError();
+    std::fill(bt.cap.begin(), bt.cap.end(), 0ull);
+    std::fill(bt.off.begin(), bt.off.end(), 0ull);
+    HIPCHK(c->out2[bt.slot].reserve(16));
   }
   return ZPAQHIP_OK;
 }
 
-int verify_sha1(zpaqhip_ctx *c, const ScanOut &so, const std::vector<zpaqhip_seg_result> &res, zpaqhip_err *err) {
-  std::vector<int> bad;
-  int rc = sha1_mismatches(c, so, res, bad, err);
+// SHA-1 of every decoded segment of a batch that stores one, computed ON THE DEVICE over the staging buffers
+// (zh_sha1_dev.hip) while the plaintext is still there; bad[s] = 1 where the digest differs from the stored one
+// (Decompresser.cs:183-191).
+int sha1_mismatches(zpaqhip_ctx *c, const Batch &bt, std::vector<int> &bad, zpaqhip_err *err) {
+  const size_t ns = bt.so.segs.size();
+  bad.assign(ns, 0);
+  // two passes: segments in the staging buffer, segments in the second-pass buffer
+  for (int where = 0; where < 2; ++where) {
+    std::vector<uint64_t> tab;
+    std::vector<uint32_t> which;
+    for (size_t b = 0; b < bt.so.blocks.size(); ++b) {
+      if ((int)(bt.off[b] >> 63) != where) continue;
+      const zpaqhip_block &B = bt.so.blocks[b];
+      for (uint32_t i = 0; i < B.n_seg; ++i) {
+        const size_t s = B.first_seg + i;
+        if (!(bt.so.segs[s].flags & 1) || bt.res[s].status != ZPAQHIP_OK) continue;
+        tab.push_back(bt.res[s].out_off);
+        tab.push_back(bt.res[s].out_len);
+        which.push_back((uint32_t)s);
+      }
+    }
+    if (which.empty()) continue;
+    const uint8_t *base = where ? (const uint8_t *)c->out_fix[bt.slot].p : (const uint8_t *)c->out2[bt.slot].p;
+    const size_t tab_bytes = tab.size() * 8, dig_bytes = which.size() * 20;
+    HIPCHK(c->sdesc.reserve(tab_bytes + dig_bytes + 64));        // the descriptors of the finished decode are not needed any more
+    uint8_t *d_tab = (uint8_t *)c->sdesc.p, *d_dig = d_tab + ((tab_bytes + 15) & ~(size_t)15);
+    HIPCHK(hipMemcpyAsync(d_tab, tab.data(), tab_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(zh_launch_sha1(base, (const uint64_t *)d_tab, (uint32_t)which.size(), (uint32_t *)d_dig, c->stream));
+    std::vector<uint32_t> dig(which.size() * 5);
+    HIPCHK(hipMemcpyAsync(dig.data(), d_dig, dig_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < which.size(); ++k) {
+      uint8_t d[20];
+      for (int i = 0; i < 5; ++i) {
+        const uint32_t v = dig[5 * k + i];
+        d[4 * i] = (uint8_t)(v >> 24); d[4 * i + 1] = (uint8_t)(v >> 16); d[4 * i + 2] = (uint8_t)(v >> 8); d[4 * i + 3] = (uint8_t)v;
+      }
+      bad[which[k]] = memcmp(d, bt.so.segs[which[k]].sha1, 20) != 0;
+    }
+  }
+  return ZPAQHIP_OK;
+}
+
+// After decode_finish: plaintext sizes, and a second decode of the blocks that did not fit their staging slot.
+int settle_batch(zpaqhip_ctx *c, Batch &bt, const zpaqhip_opts &opts, bool tolerate, zpaqhip_stats &acc, zpaqhip_err *err) {
+  const size_t nb = bt.so.blocks.size();
+  std::vector<uint32_t> redo;
+  for (size_t b = 0; b < nb; ++b) {
+    const zpaqhip_block &B = bt.so.blocks[b];
+    uint64_t real = 0;
+    bool full = false;
+    for (uint32_t i = 0; i < B.n_seg; ++i) {
+      real += bt.res[B.first_seg + i].out_len;
+      full |= bt.res[B.first_seg + i].status == ZPAQHIP_E_OUTPUT_FULL;
+    }
+    bt.real[b] = real;
+    if (full || real > bt.cap[b]) redo.push_back((uint32_t)b);
+  }
+  if (redo.empty()) return ZPAQHIP_OK;
+  // exact sizes are known now: these blocks go to a buffer of their own
+  std::vector<uint64_t> off2(redo.size()), cap2(redo.size());
+  uint64_t pos = 0;
+  for (size_t k = 0; k < redo.size(); ++k) { off2[k] = pos; cap2[k] = bt.real[redo[k]]; pos += cap2[k]; }
+  HIPCHK(c->out_fix[bt.slot].reserve((size_t)pos + 16));
+  zh_pending P;
+  int rc = decode_launch(c, c->in2[bt.slot].p, bt.h, bt.len, bt.so.blocks.data(), nb, bt.so.segs.data(), bt.so.segs.size(),
+                         redo.data(), redo.size(), c->out_fix[bt.slot].p, off2.data(), cap2.data(), opts, c->stream, P, err);
+  if (!rc) rc = decode_finish(c, P, bt.res.data(), err);
+  acc.kernel_ms += c->stats.kernel_ms; acc.launches += c->stats.launches;
+  if (rc && !(tolerate && data_error(rc)) && !data_error(rc)) return rc;
+  for (size_t k = 0; k < redo.size(); ++k) {            // mark: lives in out_fix (offset | top bit)
+    bt.off[redo[k]] = off2[k] | (1ull << 63);
+    bt.cap[redo[k]] = cap2[k];
+  }
+  return ZPAQHIP_OK;
+}
+
+const uint8_t *block_dev_ptr(zpaqhip_ctx *c, const Batch &bt, size_t b) {
+  const uint64_t o = bt.off[b];
+  return (o >> 63) ? (const uint8_t *)c->out_fix[bt.slot].p + (o & ~(1ull << 63)) : (const uint8_t *)c->out2[bt.slot].p + o;
+}
+
+// Deliver the first `upto_blocks` blocks (plus `partial` bytes of the next one) of a decoded batch to the sink, in order.
+int drain_batch(zpaqhip_ctx *c, const Batch &bt, size_t upto_blocks, uint64_t partial, Sinkk &sink, zpaqhip_err *err) {
+  struct Piece { const uint8_t *p; uint64_t n; };
+  std::vector<Piece> pieces;
+  for (size_t b = 0; b <= upto_blocks && b < bt.so.blocks.size(); ++b) {
+    const uint64_t n = b < upto_blocks ? bt.real[b] : std::min<uint64_t>(partial, bt.real[b]);
+    if (!n) continue;
+    const uint8_t *p = block_dev_ptr(c, bt, b);
+    if (!pieces.empty() && pieces.back().p + pieces.back().n == p) pieces.back().n += n;     // contiguous on the device too
+    else pieces.push_back({p, n});
+  }
+  if (sink.mem || !sink.wr) {
+    for (const Piece &pc : pieces) {
+      if (sink.total < sink.cap) {
+        const uint64_t n = std::min<uint64_t>(pc.n, sink.cap - sink.total);
+        HIPCHK(hipMemcpyAsync(sink.mem + sink.total, pc.p, (size_t)n, hipMemcpyDeviceToHost, c->s_out));
+      }
+      sink.total += pc.n;
+    }
+    return ZPAQHIP_OK;
+  }
+  // Writer form: pinned double buffer; the copy of chunk i+1 runs while write_fn consumes chunk i
+  for (int i = 0; i < 2; ++i)
+    if (!c->pin[i]) HIPCHK(hipHostMalloc((void **)&c->pin[i], kPinChunk, hipHostMallocDefault));
+  struct Chunk { uint64_t n; };
+  int cur = 0;
+  uint64_t fill[2] = {0, 0};
+  bool inflight[2] = {false, false};
+  auto flush = [&](int i) -> int {
+    if (!inflight[i]) return ZPAQHIP_OK;
+    HIPCHK(hipEventSynchronize(c->ev_pin[i]));
+    inflight[i] = false;
+    for (uint64_t p = 0; p < fill[i];) {
+      const int n = (int)std::min<uint64_t>(fill[i] - p, 1u << 30);
+      if (sink.wr(sink.user, c->pin[i] + p, n) < 0) { set_err(err, ZPAQHIP_E_CALLBACK, -1, -1); return ZPAQHIP_E_CALLBACK; }
+      p += (uint64_t)n;
+    }
+    sink.total += fill[i];
+    fill[i] = 0;
+    return ZPAQHIP_OK;
+  };
+  for (const Piece &pc : pieces) {
+    for (uint64_t done = 0; done < pc.n;) {
+      const uint64_t n = std::min<uint64_t>(pc.n - done, kPinChunk - fill[cur]);
+      HIPCHK(hipMemcpyAsync(c->pin[cur] + fill[cur], pc.p + done, (size_t)n, hipMemcpyDeviceToHost, c->s_out));
+      fill[cur] += n; done += n;
+      if (fill[cur] == kPinChunk) {
+        HIPCHK(hipEventRecord(c->ev_pin[cur], c->s_out));
+        inflight[cur] = true;
+        cur ^= 1;
+        int rc = flush(cur);                            // the other buffer must be free before it is refilled
+        if (rc) return rc;
+      }
+    }
+  }
+  if (fill[cur]) { HIPCHK(hipEventRecord(c->ev_pin[cur], c->s_out)); inflight[cur] = true; }
+  int rc = flush(cur ^ 1);
+  if (!rc) rc = flush(cur);
+  return rc;
+}
+
+struct SegSink {                          // zpaqhip_decompress_segments: per-segment records in stream order
+  std::vector<zpaqhip_seg_result> res;
+  std::vector<zpaqhip_segment> segs;
+};
+
+// The pipeline.  `tolerate`: per-segment data errors do not end the call (zpaqhip_decompress_segments).
+int run_pipeline(zpaqhip_ctx *c, Source &src, Sinkk &sink, const zpaqhip_opts &opts, bool tolerate, SegSink *segsink,
+                 zpaqhip_err *err) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->s_in) {
+    HIPCHK(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreate(&c->ev_in[i])); HIPCHK(hipEventCreate(&c->ev_pin[i])); }
+    HIPCHK(hipEventCreate(&c->ev_h0)); HIPCHK(hipEventCreate(&c->ev_h1));
+  }
+  zpaqhip_stats acc{};
+  Batch bt[2];
+  zh_pending P;
+  size_t blk0 = 0, seg0 = 0;
+  int final_rc = ZPAQHIP_OK;
+  zpaqhip_err final_err{};
+  bool have_prev = false, stop = false;
+  int cur = 0;
+  float h2d_ms = 0;
+
+  auto upload = [&](Batch &b) -> int {
+    if (b.so.blocks.empty()) return ZPAQHIP_OK;
+    HIPCHK(c->in2[b.slot].reserve(b.len + 16));
+    HIPCHK(hipEventRecord(c->ev_h0, c->s_in));
+    HIPCHK(hipMemcpyAsync(c->in2[b.slot].p, b.h, b.len, hipMemcpyHostToDevice, c->s_in));
+    HIPCHK(hipEventRecord(c->ev_h1, c->s_in));
+    HIPCHK(hipEventRecord(c->ev_in[b.slot], c->s_in));
+    return ZPAQHIP_OK;
+  };
+
+  int rc = next_batch(src, bt[cur], blk0, seg0, (size_t)opts.batch_blocks, err);
   if (rc) return rc;
-  for (size_t s = 0; s < bad.size(); ++s)
-    if (bad[s]) { set_err(err, ZPAQHIP_E_SHA1, (int)so.segs[s].block, (int)s); return ZPAQHIP_E_SHA1; }
+  bt[cur].slot = cur;
+  rc = upload(bt[cur]);
+  if (rc) return rc;
+  for (;;) {
+    Batch &B = bt[cur];
+    const bool have = !B.so.blocks.empty();
+    if (have) {
+      rc = plan_staging(c, B, err);
+      if (rc) return rc;
+      B.res.assign(B.so.segs.size(), zpaqhip_seg_result{});
+      HIPCHK(hipStreamWaitEvent(c->stream, c->ev_in[B.slot], 0));
+      rc = decode_launch(c, c->in2[B.slot].p, B.h, B.len, B.so.blocks.data(), B.so.blocks.size(), B.so.segs.data(),
+                         B.so.segs.size(), nullptr, 0, c->out2[B.slot].p, B.off.data(), B.cap.data(), opts, c->stream, P, err);
+      if (rc) { rebase_err(err, B); return rc; }
+    }
+    // ---- while the kernels run: deliver the previous batch, fetch and upload the next one
+    Batch &prev = bt[cur ^ 1];
+    if (have_prev) {
+      rc = drain_batch(c, prev, prev.so.blocks.size(), 0, sink, err);
+      if (rc) return rc;
+      have_prev = false;
+    }
+    bool more = have && !B.last;
+    if (more) {
+      { float ms = 0; if (hipEventElapsedTime(&ms, c->ev_h0, c->ev_h1) == hipSuccess) h2d_ms += ms; else (void)hipGetLastError(); }
+      HIPCHK(hipStreamSynchronize(c->s_out));          // prev's device buffers are about to be reused
+      rc = next_batch(src, prev, blk0 + B.so.blocks.size(), seg0 + B.so.segs.size(), (size_t)opts.batch_blocks, err);
+      if (rc) return rc;
+      prev.slot = cur ^ 1;
+      rc = upload(prev);
+      if (rc) return rc;
+    }
+    if (!have) {
+      if (B.rc_after) { final_rc = B.rc_after; final_err = B.err_after; rebase_err(&final_err, B); }
+      break;
+    }
+    // ---- finish this batch
+    rc = decode_finish(c, P, B.res.data(), err);
+    acc.kernel_ms += c->stats.kernel_ms; acc.launches += c->stats.launches;
+    acc.blocks += c->stats.blocks; acc.in_bytes += c->stats.in_bytes; acc.model_bytes += c->stats.model_bytes;
+    acc.concurrent = std::max(acc.concurrent, c->stats.concurrent); acc.kernel_kind = std::max(acc.kernel_kind, c->stats.kernel_kind);
+    if (rc && !data_error(rc)) { rebase_err(err, B); return rc; }
+    rc = settle_batch(c, B, opts, tolerate, acc, err);
+    if (rc) { rebase_err(err, B); return rc; }
+    if (opts.verify_sha1) {
+      std::vector<int> bad;
+      rc = sha1_mismatches(c, B, bad, err);
+      if (rc) return rc;
+      for (size_t s2 = 0; s2 < bad.size(); ++s2)
+        if (bad[s2] && B.res[s2].status == ZPAQHIP_OK) B.res[s2].status = ZPAQHIP_E_SHA1;
+    }
+    // first segment that failed: everything before it is delivered, then the call ends with its error (the reference
+    // raises on reaching the damaged segment, Decompresser.cs:121-153)
+    size_t ok_blocks = B.so.blocks.size();
+    uint64_t partial = 0;
+    if (!tolerate) {
+      for (size_t b = 0; b < B.so.blocks.size() && !stop; ++b) {
+        const zpaqhip_block &Bk = B.so.blocks[b];
+        uint64_t before = 0;
+        for (uint32_t i = 0; i < Bk.n_seg; ++i) {
+          const zpaqhip_seg_result &r = B.res[Bk.first_seg + i];
+          if (r.status != ZPAQHIP_OK) {
+            stop = true; ok_blocks = b; partial = before;
+            final_rc = r.status == ZH_E_SKIPPED ? ZPAQHIP_E_CORRUPT : r.status;
+            set_err(&final_err, final_rc, (int)(B.blk0 + b), (int)(B.seg0 + Bk.first_seg + i));
+            break;
+          }
+          before += r.out_len;
+        }
+      }
+    }
+    if (segsink) {
+      uint64_t base = sink.total;                       // stream-order offset of this batch's first byte ...
+      if (have_prev) base += 0;
+      uint64_t run = 0;
+      for (size_t b = 0; b < B.so.blocks.size(); ++b) {
+        const zpaqhip_block &Bk = B.so.blocks[b];
+        const uint64_t st_off = (B.off[b] >> 63) ? (B.off[b] & ~(1ull << 63)) : B.off[b];
+        for (uint32_t i = 0; i < Bk.n_seg; ++i) {
+          zpaqhip_seg_result r = B.res[Bk.first_seg + i];
+          r.out_off = base + run + (r.out_off - st_off);
+          segsink->res.push_back(r);
+          zpaqhip_segment sg = B.so.segs[Bk.first_seg + i];
+          sg.block += (uint32_t)B.blk0;
+          segsink->segs.push_back(sg);
+        }
+        run += B.real[b];
+      }
+    }
+    if (stop) {
+      rc = drain_batch(c, B, ok_blocks, partial, sink, err);
+      if (rc) return rc;
+      break;
+    }
+    if (!more) {
+      rc = drain_batch(c, B, B.so.blocks.size(), 0, sink, err);
+      if (rc) return rc;
+      if (B.rc_after) { final_rc = B.rc_after; final_err = B.err_after; rebase_err(&final_err, B); }
+      break;
+    }
+    have_prev = true;
+    blk0 += B.so.blocks.size(); seg0 += B.so.segs.size();
+    cur ^= 1;
+  }
+  { float ms = 0; if (hipEventElapsedTime(&ms, c->ev_h0, c->ev_h1) == hipSuccess) h2d_ms += ms; else (void)hipGetLastError(); }
+  HIPCHK(hipEventRecord(c->ev_h0, c->s_out));
+  HIPCHK(hipStreamSynchronize(c->s_out));
+  c->stats = acc;
+  c->stats.h2d_ms = h2d_ms;
+  c->stats.out_bytes = sink.total;
+  if (final_rc) { if (err) *err = final_err; return final_rc; }
   return ZPAQHIP_OK;
 }
 
@@ -556,24 +909,16 @@ int zpaqhip_decompress(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint8_t
                        const zpaqhip_opts *opts_in, zpaqhip_err *err) {
   if (!c || (!in && in_len) || !out_len || (!out && out_cap)) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
   const zpaqhip_opts opts = resolve_opts(opts_in);
-  ScanOut so;
-  std::vector<zpaqhip_seg_result> res;
-  uint64_t total = 0;
+  Source src; src.mem = in ? in : (const uint8_t *)""; src.mem_len = in_len;
+  Sinkk sink; sink.mem = out; sink.cap = out_cap;
   *out_len = 0;
-  int rc = decode_stream_to_device(c, in, in_len, opts, so, res, &total, err);
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = run_pipeline(c, src, sink, opts, false, nullptr, err);
+  c->stats.d2h_ms = 0;
+  (void)t0;
+  *out_len = (size_t)sink.total;
   if (rc) return rc;
-  *out_len = (size_t)total;
-  if (total > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, -1, -1); return ZPAQHIP_E_OUTPUT_FULL; }
-  if (opts.verify_sha1) { rc = verify_sha1(c, so, res, err); if (rc) return rc; }      // on the device, before the copy back
-  if (total) {
-    HIPCHK(hipEventRecord(c->ev0, c->stream));
-    HIPCHK(hipMemcpyAsync(out, c->out.p, total, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipEventRecord(c->ev1, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    c->stats.d2h_ms = ms;
-  }
+  if (sink.total > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, -1, -1); return ZPAQHIP_E_OUTPUT_FULL; }
   return ZPAQHIP_OK;
 }
 
@@ -585,26 +930,19 @@ int zpaqhip_decompress_segments(zpaqhip_ctx *c, const uint8_t *in, size_t in_len
     return ZPAQHIP_E_ARG;
   }
   const zpaqhip_opts opts = resolve_opts(opts_in);
-  ScanOut so;
-  std::vector<zpaqhip_seg_result> res;
-  uint64_t total = 0;
+  Source src; src.mem = in ? in : (const uint8_t *)""; src.mem_len = in_len;
+  Sinkk sink; sink.mem = out; sink.cap = out_cap;
+  SegSink ss;
   *out_len = 0; *n_results = 0;
-  int rc = decode_stream_to_device(c, in, in_len, opts, so, res, &total, err, true);
-  if (rc) return rc;
-  *out_len = (size_t)total;
-  *n_results = res.size();
-  if (res.size() > result_cap) { set_err(err, ZPAQHIP_E_ARG, -1, -1, "result table too small"); return ZPAQHIP_E_ARG; }
-  if (!res.empty()) memcpy(results, res.data(), res.size() * sizeof(zpaqhip_seg_result));
-  if (total > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, -1, -1); return ZPAQHIP_E_OUTPUT_FULL; }
-  if (total) HIPCHK(hipMemcpy(out, c->out.p, total, hipMemcpyDeviceToHost));
-  if (opts.verify_sha1) {                   // mismatches become per-segment statuses
-    std::vector<int> bad;
-    rc = sha1_mismatches(c, so, res, bad, err);
-    if (rc) return rc;
-    for (size_t s = 0; s < res.size(); ++s)
-      if (bad[s]) results[s].status = ZPAQHIP_E_SHA1;
-  }
-  return ZPAQHIP_OK;
+  int rc = run_pipeline(c, src, sink, opts, true, &ss, err);
+  *out_len = (size_t)sink.total;
+  *n_results = ss.res.size();
+  if (rc && !data_error(rc)) return rc;
+  const int frame_rc = rc;                               // a framing error after the last good block: reported below
+  if (ss.res.size() > result_cap) { set_err(err, ZPAQHIP_E_ARG, -1, -1, "result table too small"); return ZPAQHIP_E_ARG; }
+  if (!ss.res.empty()) memcpy(results, ss.res.data(), ss.res.size() * sizeof(zpaqhip_seg_result));
+  if (sink.total > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, -1, -1); return ZPAQHIP_E_OUTPUT_FULL; }
+  return frame_rc;
 }
 
 // Decompresser.pcomp (Decompresser.cs:155-158 -> ZPAQL.write(out, true), ZPAQL.cs:158-179): the PCOMP program a block's
@@ -630,7 +968,7 @@ int zpaqhip_block_pcomp(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint32
   o.struct_size = sizeof o;
   o.max_concurrent = 1;                                  // the block runs in arena slot 0
   o.kernel = 1;                                          // the generic kernel knows how to stop after the header
-  o.reserved[0] = kPpOnlyMagic;
+  o.reserved[1] = kPpOnlyMagic;
   std::vector<zpaqhip_seg_result> res(so.segs.size());
   const uint32_t id = block;
   const uint64_t off0 = 0, cap0 = 0;                     // count-only: nothing is written
@@ -659,30 +997,9 @@ int zpaqhip_decompress_cb(zpaqhip_ctx *c, zpaqhip_read_fn read_fn, zpaqhip_write
                           const zpaqhip_opts *opts_in, zpaqhip_err *err) {
   if (!c || !read_fn || !write_fn) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
   const zpaqhip_opts opts = resolve_opts(opts_in);
-  std::vector<uint8_t> in;
-  for (;;) {                                            // Reader.read until EOF (Reader.cs:14-25)
-    const int chunk = 1 << 20;
-    size_t old = in.size();
-    in.resize(old + chunk);
-    int n = read_fn(user, in.data() + old, chunk);
-    if (n < 0) { set_err(err, ZPAQHIP_E_CALLBACK, -1, -1); return ZPAQHIP_E_CALLBACK; }
-    in.resize(old + (size_t)n);
-    if (n == 0) break;
-  }
-  ScanOut so;
-  std::vector<zpaqhip_seg_result> res;
-  uint64_t total = 0;
-  int rc = decode_stream_to_device(c, in.data(), in.size(), opts, so, res, &total, err);
-  if (rc) return rc;
-  std::vector<uint8_t> out((size_t)total);
-  if (total) HIPCHK(hipMemcpy(out.data(), c->out.p, total, hipMemcpyDeviceToHost));
-  if (opts.verify_sha1) { rc = verify_sha1(c, so, res, err); if (rc) return rc; }
-  for (size_t p = 0; p < out.size();) {                 // Writer.write (Writer.cs:19-24)
-    int n = (int)std::min<size_t>(out.size() - p, 1 << 20);
-    if (write_fn(user, out.data() + p, n) < 0) { set_err(err, ZPAQHIP_E_CALLBACK, -1, -1); return ZPAQHIP_E_CALLBACK; }
-    p += (size_t)n;
-  }
-  return ZPAQHIP_OK;
+  Source src; src.rd = read_fn; src.user = user;
+  Sinkk sink; sink.wr = write_fn; sink.user = user;
+  return run_pipeline(c, src, sink, opts, false, nullptr, err);
 }
 
 }  // extern "C"

@@ -113,12 +113,8 @@ class Decompresser:
                 break
             chunks.append(b)
         self._stream = np.frombuffer(b"".join(chunks), np.uint8)
-        try:
-            self._scan = api.scan(self._stream)
-        except ZpaqError as e:
-            # framing damage: keep what precedes it, raise when the caller gets there
-            self._scan_err = e
-            self._scan = api.scan(self._stream[:0])
+        # framing damage: the blocks before it are kept, the error is raised when the caller gets there
+        self._scan, self._scan_err = api.scan(self._stream, partial=True)
         self._b = -1
 
     def _decode_all(self):

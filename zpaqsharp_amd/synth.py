@@ -108,17 +108,20 @@ def lz77_encode(data) -> np.ndarray:
 
 
 def compress_block(model, data, filename: bytes = b"", comment: Optional[bytes] = None, sha1: bool = True,
-                   tag: bool = True) -> bytes:
-    """One block / one segment in LibZPAQ.compressBlock framing (LibZPAQ.cs:296-323)."""
+                   tag: bool = True, pre=None) -> bytes:
+    """One block / one segment in LibZPAQ.compressBlock framing (LibZPAQ.cs:296-323).  `pre`: the bytes to code when the
+    caller has already run the pre-processor the block's PCOMP inverts (size comment and SHA-1 still describe `data`)."""
     m: Model = models.get(model) if isinstance(model, str) else model
     d = _u8(data)
     src = d
-    if m.pcomp_cmd.startswith("e8e9"):
+    if pre is not None:
+        src = _u8(pre)
+    elif m.pcomp_cmd.startswith("e8e9"):
         src = e8e9(d)
     elif m.pcomp_cmd.startswith("lz77"):
         src = lz77_encode(d)
     hdr, pc = _u8(m.header), _u8(m.pcomp) if m.pcomp else None
-    cap = d.size + d.size // 8 + len(m.header) + 2 * len(m.pcomp) + 4096
+    cap = max(d.size, src.size) + max(d.size, src.size) // 8 + len(m.header) + 2 * len(m.pcomp) + 4096
     need = C.c_size_t(0)
     for _ in range(2):
         out = np.empty(cap, np.uint8)
