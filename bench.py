@@ -143,11 +143,12 @@ def resident_run(z, synth, torch, ctx, dev, model_name, kind, nb, bs, threads, c
     d_in = torch.from_numpy(stream).to(dev)
     d_out = torch.zeros(nb * bs, dtype=torch.uint8, device=dev)
     off, cap = [i * bs for i in range(nb)], [bs] * nb
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rc, res = ctx.decode_blocks_device(d_in.data_ptr(), stream.size, sc, d_out.data_ptr(), off, cap, h_in=stream)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    for timed in (False, True):               # the first pass allocates the arena (tens of GB for the max model)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc, res = ctx.decode_blocks_device(d_in.data_ptr(), stream.size, sc, d_out.data_ptr(), off, cap, h_in=stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     st = ctx.stats()
     ok = all(r.status == 0 and r.out_len == bs for r in res)
     if ok:

@@ -186,6 +186,17 @@ int zpaqhip_decompress_segments(zpaqhip_ctx *ctx, const uint8_t *in, size_t in_l
 int zpaqhip_decompress_cb(zpaqhip_ctx *ctx, zpaqhip_read_fn read_fn, zpaqhip_write_fn write_fn,
                           void *user, const zpaqhip_opts *opts, zpaqhip_err *err);
 
+/* ---- whole stream on several GPUs of one node (BASELINE.json configs[3]) ----
+ * LibZPAQ.decompress(Reader, Writer) (LibZPAQ.cs:65-79) for a caller that owns more than one GPU and no
+ * torch.distributed ranks (the C# host): one context and one host thread per entry of `devices` (a device may be
+ * listed more than once), blocks dealt longest-first over them (the same plan zpaqsharp_amd/multigpu.py derives per
+ * rank), each device decodes its shard, plaintext arrives in `out` in stream order.  With a decimal size in every
+ * segment comment (LibZPAQ.compressBlock writes it, LibZPAQ.cs:298-300) every device copies its blocks straight to their
+ * final place; otherwise the shards pass through host buffers.  No context is needed or kept. */
+int zpaqhip_decompress_multi(const int *devices, size_t n_devices, const uint8_t *in, size_t in_len,
+                             uint8_t *out, size_t out_cap, size_t *out_len,
+                             const zpaqhip_opts *opts, zpaqhip_err *err);
+
 /* ---- explicit block-table form, device-resident buffers ------------------
  * Replaces the per-block inner loop Decompresser.decompress(-1)
  * (Decompresser.cs:121-153) for a set of blocks.  `d_in` is the whole stream in

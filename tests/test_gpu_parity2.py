@@ -351,3 +351,21 @@ def test_good_blocks_before_damage_are_delivered(ctx):
             if d.findBlock() and d.findFilename():
                 d.readComment()
                 d.decompress()
+
+
+def test_multi_device_entry_point_with_contexts_sharing_this_gpu(ctx):
+    """zpaqhip_decompress_multi (the C# host's way to use several GPUs): N contexts on N host threads, LPT plan, output
+    in stream order.  This box has one GPU, so the device list repeats it; sizes from the comments (direct placement),
+    missing / wrong sizes (shards through host buffers), framing damage behind good blocks."""
+    s, want = _mixed_stream(n_blocks=19, seed=3)                 # some comments carry no or a bogus size
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        assert z.decompress_multi(devs, s, verify_sha1=True).tobytes() == want, devs
+    parts = [util.text(20000 + 3000 * i, seed=50 + i) for i in range(9)]
+    s2 = b"".join(util.block(("l1", "mid", "min")[i % 3], d) for i, d in enumerate(parts))   # every block sized: placed path
+    assert z.decompress_multi([0, 0], s2, verify_sha1=True).tobytes() == b"".join(parts)
+    wrong = util.block("l1", parts[0], comment=b"5") + util.block("mid", parts[1])           # a wrong size: falls back
+    assert z.decompress_multi([0, 0], wrong, verify_sha1=True).tobytes() == parts[0] + parts[1]
+    bad = bytearray(util.block("l1", parts[2]))
+    bad[z.scan(bytes(bad)).segments[0].data_off + 30] ^= 4
+    with pytest.raises(z.ZpaqError):
+        z.decompress_multi([0, 0], s2 + bytes(bad))

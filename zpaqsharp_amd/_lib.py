@@ -59,7 +59,7 @@ WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_int)
 SYMBOLS = ("zpaqhip_version", "zpaqhip_strerror", "zpaqhip_device_count", "zpaqhip_ctx_create",
            "zpaqhip_ctx_destroy", "zpaqhip_last_stats", "zpaqhip_scan", "zpaqhip_decompress",
            "zpaqhip_decompress_segments", "zpaqhip_decompress_cb", "zpaqhip_decode_blocks_device", "zpaqhip_read_device_tables",
-           "zpaqhip_block_pcomp")
+           "zpaqhip_block_pcomp", "zpaqhip_decompress_multi")
 
 _lib = None
 
@@ -99,5 +99,6 @@ def load():
                                                C.POINTER(C.c_uint64), C.POINTER(SegResult), C.POINTER(Opts), vp, errp]
     L.zpaqhip_read_device_tables.argtypes = [vp, vp, vp, vp, vp, vp, errp]
     L.zpaqhip_block_pcomp.argtypes = [vp, vp, sz, C.c_uint32, vp, sz, C.POINTER(sz), errp]
+    L.zpaqhip_decompress_multi.argtypes = [C.POINTER(C.c_int), sz, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(Opts), errp]
     _lib = L
     return L

@@ -83,6 +83,28 @@ def scan(stream, partial: bool = False):
     return res
 
 
+def decompress_multi(devices: Sequence[int], stream, out_cap: Optional[int] = None, **opt) -> np.ndarray:
+    """zpaqhip_decompress_multi: LibZPAQ.decompress over several GPUs of one node (one context + host thread per
+    entry of `devices`; an entry may repeat), blocks dealt longest-first, plaintext in stream order."""
+    L = _lib.load()
+    a = _as_u8(stream)
+    o = make_opts(**opt)
+    err, n = Err(), C.c_size_t(0)
+    devs = (C.c_int * len(devices))(*devices)
+    if out_cap is None:
+        hints = [b.usize_hint for b in scan(a, partial=True)[0].blocks]
+        out_cap = sum(h for h in hints if h != UINT64_MAX) if hints and all(h != UINT64_MAX for h in hints) else 0
+    out = np.empty(max(1, out_cap), np.uint8)
+    rc = L.zpaqhip_decompress_multi(devs, len(devices), a.ctypes.data, a.size, out.ctypes.data, out_cap, C.byref(n), C.byref(o), C.byref(err))
+    if rc == -20 and n.value > out_cap:
+        out_cap = n.value
+        out = np.empty(max(1, out_cap), np.uint8)
+        rc = L.zpaqhip_decompress_multi(devs, len(devices), a.ctypes.data, a.size, out.ctypes.data, out_cap, C.byref(n), C.byref(o), C.byref(err))
+    if rc:
+        _raise(err, rc)
+    return out[:n.value]
+
+
 def make_opts(verify_sha1: bool = False, max_concurrent: int = 0, kernel: int = 0, zpaql_budget: int = 0,
               batch_blocks: int = 0) -> Opts:
     o = Opts()

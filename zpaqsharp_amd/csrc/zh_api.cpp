@@ -510,6 +510,10 @@ struct Sinkk {
   zpaqhip_write_fn wr = nullptr;          // callback form (Writer.write, Writer.cs:19-24)
   void *user = nullptr;
   uint64_t total = 0;                     // plaintext bytes so far (counted past `cap` too)
+  // multi-device form: block k of this source goes to mem + place[k] (sizes promised by the caller); sizes[k] = what
+  // it really produced
+  const uint64_t *place = nullptr;
+  std::vector<uint64_t> *sizes = nullptr;
 };
 
 constexpr size_t kBatchMinBlocks = 256, kBatchMinBytes = 32u << 20, kBatchMaxBlocks = 4096;
@@ -699,6 +703,16 @@ int drain_batch(zpaqhip_ctx *c, const Batch &bt, size_t upto_blocks, uint64_t pa
     const uint8_t *p = block_dev_ptr(c, bt, b);
     if (!pieces.empty() && pieces.back().p + pieces.back().n == p) pieces.back().n += n;     // contiguous on the device too
     else pieces.push_back({p, n});
+  }
+  if (sink.place) {                                     // placed form: every block at its own offset
+    for (size_t b = 0; b < upto_blocks && b < bt.so.blocks.size(); ++b) {
+      const uint64_t n = bt.real[b], at = sink.place[bt.blk0 + b];
+      if (sink.sizes) (*sink.sizes)[bt.blk0 + b] = n;
+      if (n && at < sink.cap)
+        HIPCHK(hipMemcpyAsync(sink.mem + at, block_dev_ptr(c, bt, b), (size_t)std::min<uint64_t>(n, sink.cap - at), hipMemcpyDeviceToHost, c->s_out));
+      sink.total += n;
+    }
+    return ZPAQHIP_OK;
   }
   if (sink.mem || !sink.wr) {
     for (const Piece &pc : pieces) {
@@ -919,6 +933,133 @@ int zpaqhip_decompress(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint8_t
   *out_len = (size_t)sink.total;
   if (rc) return rc;
   if (sink.total > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, -1, -1); return ZPAQHIP_E_OUTPUT_FULL; }
+  return ZPAQHIP_OK;
+}
+
+// Several GPUs of one node: one context and one host thread per entry of `devices`; blocks dealt longest-first.
+int zpaqhip_decompress_multi(const int *devices, size_t n_dev, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                             size_t *out_len, const zpaqhip_opts *opts_in, zpaqhip_err *err) {
+  if (!devices || !n_dev || (!in && in_len) || !out_len || (!out && out_cap)) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
+  const zpaqhip_opts opts = resolve_opts(opts_in);
+  *out_len = 0;
+  ScanOut so;
+  zpaqhip_err scan_err{};
+  const int scan_rc = scan_stream(in ? in : (const uint8_t *)"", in_len, so, &scan_err);   // blocks before damage are decoded
+  const size_t nb = so.blocks.size();
+  // ---- the plan: longest processing time first, ties by block index (== multigpu.lpt_assign)
+  std::vector<uint64_t> weight(nb, 0);
+  for (size_t b = 0; b < nb; ++b)
+    for (uint32_t i = 0; i < so.blocks[b].n_seg; ++i) weight[b] += so.segs[so.blocks[b].first_seg + i].data_len;
+  std::vector<size_t> order(nb);
+  std::iota(order.begin(), order.end(), (size_t)0);
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight[a] > weight[b]; });
+  std::vector<std::vector<size_t>> shard(n_dev);
+  std::vector<uint64_t> load(n_dev, 0);
+  for (size_t b : order) {
+    size_t r = 0;
+    for (size_t k = 1; k < n_dev; ++k) if (load[k] < load[r]) r = k;
+    shard[r].push_back(b); load[r] += weight[b];
+  }
+  for (auto &sh : shard) std::sort(sh.begin(), sh.end());
+  // ---- placement: with a plausible size in every comment the final offsets are known up front and every device copies
+  // its blocks straight to their place; otherwise (or when a size turns out wrong) shards go through host buffers
+  bool hinted = true;
+  std::vector<uint64_t> final_off(nb + 1, 0);
+  for (size_t b = 0; b < nb; ++b) {
+    const uint64_t h = so.blocks[b].usize_hint;
+    if (h == UINT64_MAX || h > (1ull << 40)) hinted = false;
+    final_off[b + 1] = final_off[b] + (hinted ? h : 0);
+  }
+  struct Job { int rc = 0; zpaqhip_err err{}; std::vector<uint64_t> sizes; std::vector<uint8_t> sub, tmp; std::vector<uint64_t> place; uint64_t total = 0; };
+  std::vector<Job> jobs(n_dev);
+  auto run = [&](size_t r, bool placed) {
+    Job &J = jobs[r];
+    J.rc = 0; J.total = 0;
+    J.sizes.assign(shard[r].size(), 0);
+    if (shard[r].empty()) return;
+    if (J.sub.empty())
+      for (size_t b : shard[r]) J.sub.insert(J.sub.end(), in + so.blocks[b].tag_off, in + so.blocks[b].end_off);
+    zpaqhip_ctx *c = nullptr;
+    J.rc = zpaqhip_ctx_create(devices[r], &c, &J.err);
+    if (J.rc) return;
+    Source src; src.mem = J.sub.data(); src.mem_len = J.sub.size();
+    Sinkk sink;
+    if (placed) {
+      J.place.clear();
+      for (size_t b : shard[r]) J.place.push_back(final_off[b]);
+      sink.mem = out; sink.cap = out_cap; sink.place = J.place.data(); sink.sizes = &J.sizes;
+    } else {
+      uint64_t guess = 0;
+      for (size_t b : shard[r]) guess += weight[b] * 4 + 65536;
+      J.tmp.resize((size_t)guess);
+      sink.mem = J.tmp.data(); sink.cap = J.tmp.size();
+    }
+    SegSink ss;
+    J.rc = run_pipeline(c, src, sink, opts, false, placed ? nullptr : &ss, &J.err);
+    if (!placed && !J.rc && sink.total > sink.cap) {             // the guess was too small: now the size is known
+      J.tmp.resize((size_t)sink.total);
+      Source src2; src2.mem = J.sub.data(); src2.mem_len = J.sub.size();
+      Sinkk sink2; sink2.mem = J.tmp.data(); sink2.cap = J.tmp.size();
+      ss = SegSink();
+      J.rc = run_pipeline(c, src2, sink2, opts, false, &ss, &J.err);
+      sink.total = sink2.total;
+    }
+    if (!placed && !J.rc) {                                       // sizes per block from the per-segment records
+      size_t k = 0;
+      std::vector<uint64_t> per(shard[r].size(), 0);
+      for (size_t i = 0; i < ss.res.size(); ++i) { if (ss.segs[i].block < per.size()) per[ss.segs[i].block] += ss.res[i].out_len; (void)k; }
+      J.sizes = per;
+    }
+    J.total = sink.total;
+    zpaqhip_ctx_destroy(c);
+  };
+  auto run_all = [&](bool placed) {
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < n_dev; ++r) th.emplace_back(run, r, placed);
+    for (auto &t : th) t.join();
+  };
+  auto first_error = [&]() -> int {                                // the error the reference would reach first
+    int rc = 0; long best = -1;
+    for (size_t r = 0; r < n_dev; ++r) {
+      if (!jobs[r].rc) continue;
+      long g = jobs[r].err.block >= 0 && (size_t)jobs[r].err.block < shard[r].size() ? (long)shard[r][jobs[r].err.block] : 0;
+      if (best < 0 || g < best) { best = g; rc = jobs[r].rc; if (err) { *err = jobs[r].err; err->block = (int32_t)g; err->segment = -1; } }
+    }
+    return rc;
+  };
+  bool placed_ok = false;
+  if (hinted && nb) {
+    run_all(true);
+    int rc = first_error();
+    if (rc && !data_error(rc)) return rc;
+    if (!rc) {
+      placed_ok = true;
+      for (size_t r = 0; r < n_dev && placed_ok; ++r)
+        for (size_t k = 0; k < shard[r].size(); ++k)
+          if (jobs[r].sizes[k] != so.blocks[shard[r][k]].usize_hint) { placed_ok = false; break; }
+    } else return rc;
+  }
+  if (!placed_ok && nb) {                                           // no sizes in the comments, or a wrong one
+    run_all(false);
+    int rc = first_error();
+    if (rc) return rc;
+    std::vector<uint64_t> real(nb, 0);
+    for (size_t r = 0; r < n_dev; ++r)
+      for (size_t k = 0; k < shard[r].size(); ++k) real[shard[r][k]] = jobs[r].sizes[k];
+    for (size_t b = 0; b < nb; ++b) final_off[b + 1] = final_off[b] + real[b];
+    if (final_off[nb] <= out_cap)
+      for (size_t r = 0; r < n_dev; ++r) {
+        uint64_t at = 0;
+        for (size_t k = 0; k < shard[r].size(); ++k) {
+          const size_t b = shard[r][k];
+          if (real[b]) memcpy(out + final_off[b], jobs[r].tmp.data() + at, (size_t)real[b]);
+          at += real[b];
+        }
+      }
+  }
+  *out_len = (size_t)final_off[nb];
+  if (final_off[nb] > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, -1, -1); return ZPAQHIP_E_OUTPUT_FULL; }
+  if (scan_rc) { if (err) *err = scan_err; return scan_rc; }
   return ZPAQHIP_OK;
 }
 

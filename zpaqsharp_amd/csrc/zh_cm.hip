@@ -114,19 +114,28 @@ __device__ __forceinline__ uint32_t p16_of(const CmLds &S, uint32_t cm) {
   return (uint32_t)S.sq[st + 2048] * 2 + 1;
 }
 
-// Window <-> table (reference layout in HBM: 512 entries per window; group 0 = uint4 0..3, groups 16..31 = uint4 64..127)
+// Window <-> table.  A window is 512 entries = 2 KiB of the reference table; this kernel only ever touches group 0
+// (uint4 0..3) and groups 16..31 (uint4 64..127) of it, so the 960 bytes in between are free: the HBM copy of a window
+// carries its probability cache there (p16A at uint4 4..5, p16B at uint4 8..39).  A window that comes back from HBM is
+// then usable at once — the miss path has no table walk (stretch, squash) for its 272 entries.
 __device__ __forceinline__ void win_store(const CmLds &S, uint32_t slot, uint32_t *table, uint32_t w, uint32_t lane) {
   uint4 *g = reinterpret_cast<uint4 *>(table + (uint64_t)w * 512);
   g[64 + lane] = reinterpret_cast<const uint4 *>(&S.winB[slot][0])[lane];
   if (lane < 4) g[lane] = reinterpret_cast<const uint4 *>(&S.winA[slot][0])[lane];
+  if (lane < 32) g[8 + lane] = reinterpret_cast<const uint4 *>(&S.p16B[slot][0])[lane];
+  if (lane >= 32 && lane < 34) g[4 + lane - 32] = reinterpret_cast<const uint4 *>(&S.p16A[slot][0])[lane - 32];
 }
 __device__ __forceinline__ void win_load(CmLds &S, uint32_t slot, const uint32_t *table, uint32_t w, uint32_t lane) {
   const uint4 *g = reinterpret_cast<const uint4 *>(table + (uint64_t)w * 512);
   const uint4 b = g[64 + lane];
-  uint4 a = make_uint4(0, 0, 0, 0);
+  uint4 a = make_uint4(0, 0, 0, 0), p = a;
   if (lane < 4) a = g[lane];
+  if (lane < 32) p = g[8 + lane];
+  if (lane >= 32 && lane < 34) p = g[4 + lane - 32];
   reinterpret_cast<uint4 *>(&S.winB[slot][0])[lane] = b;
   if (lane < 4) reinterpret_cast<uint4 *>(&S.winA[slot][0])[lane] = a;
+  if (lane < 32) reinterpret_cast<uint4 *>(&S.p16B[slot][0])[lane] = p;
+  if (lane >= 32 && lane < 34) reinterpret_cast<uint4 *>(&S.p16A[slot][0])[lane - 32] = p;
 }
 // probability cache of one slot from its entries (whole wave)
 __device__ __forceinline__ void p16_rebuild(CmLds &S, uint32_t slot, uint32_t lane) {
@@ -251,14 +260,16 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
         {                                                  // request the new window first, write the victim back while it travels
           const uint4 *g = reinterpret_cast<const uint4 *>(table + (uint64_t)neww * 512);
           const uint4 nb = g[64 + lane];
-          uint4 na = make_uint4(0, 0, 0, 0);
+          uint4 na = make_uint4(0, 0, 0, 0), np = na;
           if (lane < 4) na = g[lane];
+          if (lane < 32) np = g[8 + lane];                  // its probability cache travels with it (win_store)
+          if (lane >= 32 && lane < 34) np = g[4 + lane - 32];
           if (oldw != kNoWin) win_store(S, slot, table, oldw, lane);
           reinterpret_cast<uint4 *>(&S.winB[slot][0])[lane] = nb;
           if (lane < 4) reinterpret_cast<uint4 *>(&S.winA[slot][0])[lane] = na;
+          if (lane < 32) reinterpret_cast<uint4 *>(&S.p16B[slot][0])[lane] = np;
+          if (lane >= 32 && lane < 34) reinterpret_cast<uint4 *>(&S.p16A[slot][0])[lane - 32] = np;
         }
-        wave_sync();
-        p16_rebuild(S, slot, lane);
         ++u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         lds_st(&S.b_seq, u);
@@ -336,6 +347,14 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
       const uint4 v = make_uint4(0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u);
       uint4 *q = reinterpret_cast<uint4 *>(table);
       for (uint64_t i = lane; i < cm_bytes / 16; i += 64) q[i] = v;
+      // ... and the probability cache every window carries in HBM (win_store): predict()*2+1 of a fresh entry
+      const uint32_t pv = p16_of(S, 0x80000000u), pp = pv | pv << 16;
+      const uint4 ppat = make_uint4(pp, pp, pp, pp);
+      const uint64_t nwin = cm_bytes / 2048;
+      for (uint64_t i = lane; i < nwin * 34; i += 64) {
+        const uint64_t w = i / 34, k = i % 34;
+        q[w * 128 + (k < 32 ? 8 + k : 4 + (k - 32))] = ppat;
+      }
       const uint64_t h_off = uni64(M->h_off), tail = uni64(M->arena_bytes) - h_off;
       uint4 *z = reinterpret_cast<uint4 *>(slot_mem + h_off);
       for (uint64_t i = lane; i < tail / 16; i += 64) z[i] = make_uint4(0, 0, 0, 0);
@@ -418,7 +437,10 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
           else {                                        // swap the window in (wave A alone: nothing is in flight)
             slot = uni(pick_victim(tag, lastuse, t));
             const uint32_t old = rdlane(tag, slot);
-            if (old != kNoWin) win_store(S, slot, table, old, lane);
+            if (old != kNoWin) {
+              if (rdlane(stale, slot)) { p16_rebuild(S, slot, lane); wave_sync(); }   // trained here, cache not refreshed yet
+              win_store(S, slot, table, old, lane);
+            }
             win_load(S, slot, table, w, lane);
             tag = lane == slot ? w : tag;
             wave_sync();
