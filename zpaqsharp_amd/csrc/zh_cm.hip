@@ -271,8 +271,11 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
           if (lane >= 32 && lane < 34) reinterpret_cast<uint4 *>(&S.p16A[slot][0])[lane - 32] = np;
         }
         ++u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        lds_st(&S.b_seq, u);
+        // LDS data, then LDS flag, in program order (lds_order): no fence — a release fence here would also wait for the
+        // victim's write-back, a full store round trip that wave A has no reason to sit through (only this wave ever
+        // reads that window back, and its own memory operations stay in order)
+        lds_order();
+        lds_put0(&S.b_seq, u);
       } else {                                             // LEAVE: hand the output state back
         out_flush(ob, lane);
         if (PROF && lane == 0 && L.debug) {
