@@ -75,6 +75,7 @@
 // v250:v251 four second-nibble probabilities / selected one   v252 first-nibble probabilities, scratch
 #define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, avail_, mask_, hs_, ring_, bsa_, cur_, tag_, lid_, la_, lb_) \
   asm volatile(                                                       \
+  ".p2align 8\n"                                                      \
   ".Lzh_byte_%=:\n\t"                                                 \
   /* window lookup: lane s of `tag` holds the window id cached in slot s */ \
   "s_and_b32 s81, %[h0], %[mask]\n\t"                                 \
