@@ -25,7 +25,7 @@ from zpaqsharp_amd import models, zpaql  # noqa: E402
 
 # Every value of a ZPAQL machine is wave-uniform on the device; ZH_UNI (v_readfirstlane) tells the compiler so at the
 # places where it cannot see it (function entry, memory reads), and the whole program then runs on the scalar unit.
-SRC = ["a", "b", "c", "d", "ZH_UNI((uint32_t)M[b & mmask])", "ZH_UNI((uint32_t)M[c & mmask])", "ZH_UNI(H[d & hmask])"]
+SRC = ["a", "b", "c", "d", "zh_uni<MP>((uint32_t)M[b & mmask])", "zh_uni<MP>((uint32_t)M[c & mmask])", "zh_uni<MP>(H[d & hmask])"]
 ALU = ["a += {s};", "a -= {s};", "a *= {s};", "{{ uint32_t s_ = {s}; a = s_ ? a / s_ : 0; }}",
        "{{ uint32_t s_ = {s}; a = s_ ? a % s_ : 0; }}", "a &= {s};", "a &= ~({s});", "a |= {s};", "a ^= {s};",
        "a <<= (({s}) & 31);", "a >>= (({s}) & 31);", "f = a == ({s});", "f = a < ({s});", "f = a > ({s});"]
@@ -85,7 +85,7 @@ def translate(code: bytes, name: str) -> str:
            "template <class MP, class HP>",
            f"ZH_HD inline __attribute__((always_inline)) int zh_native_{name}(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, uint32_t &f, uint32_t input,",
            "    MP M, uint32_t mmask, HP H, uint32_t hmask, uint32_t *R, zhcore::Sink *out, uint64_t budget) {",
-           "  a = ZH_UNI(input); b = ZH_UNI(b); c = ZH_UNI(c); d = ZH_UNI(d); f = ZH_UNI(f);",
+           "  a = zh_uni<MP>(input); b = zh_uni<MP>(b); c = zh_uni<MP>(c); d = zh_uni<MP>(d); f = zh_uni<MP>(f);",
            "  (void)R; (void)out; (void)budget; (void)f;"]
     for pc in starts:
         op = code[pc]
@@ -97,7 +97,7 @@ def translate(code: bytes, name: str) -> str:
             if x == 7:
                 off = ((arg + 128) & 255) - 128
                 if ddd < 4:
-                    st = f"{'abcd'[ddd]} = ZH_UNI(R[{arg}]);"
+                    st = f"{'abcd'[ddd]} = zh_uni<MP>(R[{arg}]);"
                 elif ddd == 4:
                     st = f"if (f) {{ {jump(nxt + off, pc)} }}"
                 elif ddd == 5:
@@ -108,8 +108,8 @@ def translate(code: bytes, name: str) -> str:
                     st = jump(nxt + off, pc)
             elif ddd == 7:
                 st = {0: "return 0;", 1: "if (out) zhcore::sink_put(*out, a & 255);",
-                      3: "a = (a + ZH_UNI((uint32_t)M[b & mmask]) + 512u) * 773u;",
-                      4: "H[d & hmask] = (ZH_UNI(H[d & hmask]) + a + 512u) * 773u;"}.get(x, "return ZH_E_ZPAQL;")
+                      3: "a = (a + zh_uni<MP>((uint32_t)M[b & mmask]) + 512u) * 773u;",
+                      4: "H[d & hmask] = (zh_uni<MP>(H[d & hmask]) + a + 512u) * 773u;"}.get(x, "return ZH_E_ZPAQL;")
             elif x > 4 or op == 0:
                 st = "return ZH_E_ZPAQL;"
             else:
@@ -151,7 +151,11 @@ def main():
              "#pragma once", "#include <stdint.h>", "#include <string.h>", "", '#include "zh_core.h"', "",
              "#if defined(__HIPCC__)", "#pragma clang diagnostic push", '#pragma clang diagnostic ignored "-Wunused-label"', "#endif",
              "#if defined(__HIP_DEVICE_COMPILE__)", "#define ZH_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))", "#else",
-             "#define ZH_UNI(x) ((uint32_t)(x))", "#endif", ""]
+             "#define ZH_UNI(x) ((uint32_t)(x))", "#endif",
+             "// The M accessor type decides whether the machine's values are wave-uniform (the decoder's own run: pinned to the",
+             "// scalar unit) or per-lane (zh_chain2.hip runs a program for 16 candidate input bytes at once, one per lane).",
+             "template <class MP> struct ZhUniform { static constexpr bool value = true; };",
+             "template <class MP> ZH_HD inline __attribute__((always_inline)) uint32_t zh_uni(uint32_t x) { return ZhUniform<MP>::value ? ZH_UNI(x) : x; }", ""]
     for name, code in items:
         lines.append(translate(code, name))
         lines.append("")

@@ -75,7 +75,7 @@ namespace {
     }                                                                         \
   } while (0)
 
-constexpr size_t kQueueBytes = 256, kDebugBytes = 64;    // work-queue heads (32 B per family) and the *_prof kernels' sums
+constexpr size_t kQueueBytes = 256, kDebugBytes = 128;    // work-queue heads (32 B per family) and the *_prof kernels' sums
 constexpr uint64_t kPpOnlyMagic = 0x5A50505F4F4E4C59ull;   // internal: zpaqhip_block_pcomp -> decode_blocks_device ("ZPP_ONLY")
 
 zpaqhip_opts resolve_opts(const zpaqhip_opts *o) {
@@ -386,11 +386,11 @@ static int decode_finish(zpaqhip_ctx *c, zh_pending &P, zpaqhip_seg_result *resu
   const uint64_t total_in = P.total_in, total_model = P.total_model;
   const uint32_t launches = P.launches, slots = P.slots, kind_used = P.kind_used;
   if (P.prof) {
-    uint64_t dbg[8];
+    uint64_t dbg[16];
     HIPCHK(hipStreamSynchronize(stream));
-    HIPCHK(hipMemcpy(dbg, (uint8_t *)c->queue.p + kQueueBytes, 64, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dbg, (uint8_t *)c->queue.p + kQueueBytes, kDebugBytes, hipMemcpyDeviceToHost));
     fprintf(stderr, "ZPAQHIP_PROF cycles:");
-    for (int i = 0; i < 8; ++i) fprintf(stderr, " %llu", (unsigned long long)dbg[i]);
+    for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", (unsigned long long)dbg[i]);
     fprintf(stderr, "\n");
   }
   std::vector<ZhSegResult> res(n_segs);

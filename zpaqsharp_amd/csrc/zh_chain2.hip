@@ -41,15 +41,17 @@ namespace {
 
 // ---- compile-time description of the three models (lane = component index) --------------------------------------
 struct C2Min {                               // 0 icm 16 ; 1 isse 19 0
-  static constexpr uint32_t id = 1, n = 2, depth = 1, final_lane = 1, nmix = 0;
+  static constexpr uint32_t id = 1, n = 2, depth = 1, final_lane = 1, nmix = 0, hh = 1, hm = 2;
   static constexpr uint64_t icm = 0x1, isse = 0x2;
+  static constexpr bool helper = true;
   static constexpr int match_lane = -1;
   static constexpr uint32_t mix_lane[2] = {0, 0}, mix_j0[2] = {0, 0}, mix_m[2] = {0, 0};
   static constexpr bool has_tail = false;
 };
 struct C2Mid {                               // 0 icm ; 1-5 isse ; 6 match ; 7 mix 16 0 7 24 255
-  static constexpr uint32_t id = 2, n = 8, depth = 5, final_lane = 7, nmix = 1;
+  static constexpr uint32_t id = 2, n = 8, depth = 5, final_lane = 7, nmix = 1, hh = 3, hm = 3;
   static constexpr uint64_t icm = 0x01, isse = 0x3e;
+  static constexpr bool helper = true;
   static constexpr int match_lane = 6;
   static constexpr uint32_t mix_lane[2] = {7, 0}, mix_j0[2] = {0, 0}, mix_m[2] = {7, 0};
   static constexpr bool has_tail = false;
@@ -60,7 +62,8 @@ typedef uint32_t v4u_ __attribute__((ext_vector_type(4)));
 struct C2Max {                               // Compressor.cs:60-72: 0 const; 1 icm; 2-7 isse; 8 match; 9 icm; 10 isse; 11-14 icm;
                                              // 15 mix 16 0 15 24 255; 16 mix 8 0 16 10 255; 17 mix2 0 15 16 24 0; 18 sse 8 17 32 255;
                                              // 19 mix2 8 17 18 16 255; 20 sse 16 19 32 255; 21 mix2 0 19 20 16 0
-  static constexpr uint32_t id = 3, n = 22, depth = 6, final_lane = 21, nmix = 2;
+  static constexpr uint32_t id = 3, n = 22, depth = 6, final_lane = 21, nmix = 2, hh = 5, hm = 9;
+  static constexpr bool helper = false;      // (its LDS is full: 157 KB; the helper wave's staging does not fit yet)
   static constexpr uint64_t icm = (1u << 1) | (1u << 9) | (1u << 11) | (1u << 12) | (1u << 13) | (1u << 14), isse = 0xfcu | (1u << 10);
   static constexpr int match_lane = 8;
   static constexpr uint32_t mix_lane[2] = {15, 16}, mix_j0[2] = {0, 0}, mix_m[2] = {15, 16};
@@ -73,7 +76,9 @@ struct C2Max {                               // Compressor.cs:60-72: 0 const; 1 
 constexpr int kHWords = 256, kMBytes = 4096, kCodeBytes = 2048, kPHWords = 256, kPMBytes = 1024;
 constexpr int kEntUnits = 15;                 // ICM / ISSE entry tables of 256 x 8 bytes
 
-struct alignas(16) C2Lds {
+constexpr int kSpecUnits = 8, kSpecH = 8;      // helper wave staging: ICM/ISSE components and H words per candidate (min / mid)
+template <bool TAIL, bool HELP>
+struct alignas(16) C2LdsT {
   int16_t stretch[32768];                     // at LDS offset 0 of this struct: see lds_stretch()
   uint16_t squash[4096];
   int32_t dt[1024];
@@ -84,8 +89,14 @@ struct alignas(16) C2Lds {
   v4u_ zrow;                                 // all-zero row read by lanes without a hash table
   v2u_ lent[64];                             // per-lane entry cell of those lanes
   uint32_t lsink[64];                         // per-lane sink for their bit-history writes
-  uint32_t sse18[256 * 32];                   // max: the table of `sse 8 17` (h = 0: row = c8), Predictor.cs:163-164
-  uint16_t a19[256];                          // max: the weights of `mix2 8 17 18`
+  uint32_t sse18[TAIL ? 256 * 32 : 1];        // max: the table of `sse 8 17` (h = 0: row = c8), Predictor.cs:163-164
+  uint16_t a19[TAIL ? 256 : 2];               // max: the weights of `mix2 8 17 18`
+  // helper wave (HELP): what it prepares for the NEXT byte, for each of the 16 values the current byte can still take
+  uint32_t hspec[HELP ? kSpecH : 1][16];      // H[d] after HCOMP(candidate)
+  v4u_ rowst[HELP ? kSpecUnits : 1][3][16];   // the three candidate hash rows of every ICM / ISSE for c8 = 1
+  uint32_t mixst[HELP ? 2 : 1][16][16];       // the mixer rows for c8 = 1
+  uint32_t mb_nib, mb_byte, mb_ready;         // A -> B: seq << 8 | first nibble / byte;  B -> A: seq whose staging is complete
+  uint32_t mb_cmd, mb_ack, mb_model;          // A -> B: block start / end / exit
   uint32_t hreg[kHWords];
   uint8_t mreg[kMBytes];
   uint32_t r[256], pr[256];
@@ -95,7 +106,7 @@ struct alignas(16) C2Lds {
   Vm hz, pz;
   Sink sink;
 };
-static_assert(sizeof(C2Lds) <= 163840, "LDS budget");
+static_assert(sizeof(C2LdsT<true, false>) <= 163840 && sizeof(C2LdsT<false, true>) <= 163840, "LDS budget");
 
 typedef __attribute__((address_space(3))) uint8_t *lds_u8_p;
 typedef __attribute__((address_space(3))) uint16_t *lds_u16_p;
@@ -160,6 +171,184 @@ struct MView {
 
 constexpr uint32_t kOob = 0x80000000u;        // buffer offset beyond every arena slot of this family (< 2 GiB): dropped
 
+
+// ---- speculative HCOMP (helper wave): the translated program runs once for 16 candidate input bytes, one per lane --------
+// M: the committed bytes (LDS) under ONE shadow write per run (the three built-in programs store the input byte once);
+// H: local array, written entries shadow the committed words (LDS).  All of a, b, c, d, f are per-lane copies.
+struct SpecM {
+  lds_u8_p base;
+  uint32_t *wi, *wv, *wn;
+  struct Ref {
+    const SpecM *m; uint32_t i;
+    __device__ __forceinline__ operator uint32_t() const { return (*m->wn && *m->wi == i) ? *m->wv : (uint32_t)m->base[i]; }
+    __device__ __forceinline__ const Ref &operator=(uint32_t x) const { *m->wi = i; *m->wv = x & 255u; *m->wn = 1u; return *this; }
+  };
+  __device__ __forceinline__ Ref operator[](uint32_t i) const { return Ref{this, i}; }
+};
+template <int NH>
+struct SpecH {
+  lds_u32_p base;
+  uint32_t *hs, *wmask;
+  struct Ref {
+    const SpecH *h; uint32_t d;
+    __device__ __forceinline__ operator uint32_t() const { return ((*h->wmask >> d) & 1u) ? h->hs[d] : h->base[d]; }
+    __device__ __forceinline__ const Ref &operator=(uint32_t x) const { h->hs[d] = x; *h->wmask |= 1u << d; return *this; }
+  };
+  __device__ __forceinline__ Ref operator[](uint32_t d) const { return Ref{this, d}; }
+};
+}  // namespace
+template <> struct ZhUniform<SpecM> { static constexpr bool value = false; };
+namespace {
+
+__device__ __forceinline__ uint32_t c2_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// one dword into LDS from lane 0 (all lanes enabled around it).  The LDS unit serves a CU's requests in arrival order and a
+// wave issues them in program order, so data written before this flag is seen by whoever sees the flag (as in zh_cm.hip).
+__device__ __forceinline__ void c2_put0(const uint32_t *where, uint32_t val) {
+  const uint32_t addr = (uint32_t)(uintptr_t)where;
+  asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(val) : "memory");
+}
+enum : uint32_t { kC2New = 1, kC2End = 2, kC2Exit = 3 };
+constexpr uint32_t kC2Spin = 1u << 26;            // bounded waits: nothing may hang the GPU
+
+// k-th ICM / ISSE component of a model (compile-time)
+template <class SP>
+__device__ constexpr uint32_t c2_unit_comp(uint32_t k) {
+  uint32_t seen = 0;
+  for (uint32_t i = 0; i < 64; ++i)
+    if (((SP::icm | SP::isse) >> i) & 1) { if (seen == k) return i; ++seen; }
+  return 0;
+}
+template <class SP>
+__device__ constexpr uint32_t c2_units() {
+  uint32_t n = 0;
+  for (uint32_t i = 0; i < 64; ++i) n += ((SP::icm | SP::isse) >> i) & 1;
+  return n;
+}
+
+// Wave B of a two-wave block: while wave A decodes the second nibble of byte s, B runs HCOMP for the 16 bytes s can still
+// become, and brings what byte s+1 will start with — h[], the three candidate hash rows of every ICM / ISSE for c8 = 1,
+// the mixer row — into LDS for each of them.  When A knows byte s it takes the matching column; B commits that
+// candidate's machine state.  B never decides anything: a late B only makes A wait.
+template <class SP, class LDS>
+__device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
+  constexpr uint32_t NU = c2_units<SP>(), NH = 1u << SP::hh;
+  static_assert(NU <= (uint32_t)kSpecUnits && NH <= (uint32_t)kSpecH, "staging size");
+  uint8_t *slot_mem = L.arena + (uint64_t)blockIdx.x * L.arena_stride;
+  const uint32_t cand = lane & 15u, grp = lane >> 4;
+  uint32_t seen_cmd = 0;
+  for (;;) {
+    uint32_t cmd, sp = 0;
+    while ((cmd = c2_ld(&S.mb_cmd)) == seen_cmd) { __builtin_amdgcn_s_sleep(4); if (++sp > kC2Spin) return; }
+    seen_cmd = cmd;
+    if ((cmd & 3u) == kC2Exit) return;
+    if ((cmd & 3u) != kC2New) continue;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const ZhModel *M = &L.models[uni(c2_ld(&S.mb_model))];
+    const uint32_t arena_bytes = uni((uint32_t)M->arena_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slot_mem, 0, (int)arena_bytes, 0x00020000);
+    // this lane's units: u = grp, grp + 4 (rows of unit u for candidate `cand`)
+    uint32_t u_hto[2], u_mask[2], u_sb2[2], u_comp[2];
+    bool u_on[2];
+#pragma unroll
+    for (uint32_t r = 0; r < 2; ++r) {
+      const uint32_t u = grp + 4u * r;
+      u_on[r] = u < NU;
+      uint32_t ci = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < NU; ++k) if (k == u) ci = c2_unit_comp<SP>(k);
+      const ZhComp *cp = &M->comp[ci];
+      u_comp[r] = ci; u_hto[r] = (uint32_t)cp->ht_off; u_mask[r] = cp->ht_mask; u_sb2[r] = (uint32_t)cp->arg[0] + 2u;
+    }
+    uint32_t mx_base[2] = {0, 0}, mx_size1[2] = {0, 0};
+#pragma unroll
+    for (uint32_t q = 0; q < SP::nmix; ++q) {
+      const ZhComp &mc = M->comp[SP::mix_lane[q]];
+      mx_base[q] = uni((uint32_t)mc.cm_off); mx_size1[q] = uni(mc.cm_mask);
+    }
+    uint32_t ha = 0, hb = 0, hc = 0, hd = 0, hf = 0;      // committed HCOMP registers (M and H: S.mreg / S.hreg, zeroed by A)
+    c2_put0(&S.mb_ack, cmd);
+    uint32_t seq = 1;
+    bool alive = true;
+    while (alive) {
+      // ---- the first nibble of byte #seq
+      uint32_t v;
+      sp = 0;
+      while (((v = c2_ld(&S.mb_nib)) >> 8) != seq) {
+        if (c2_ld(&S.mb_cmd) != seen_cmd || ++sp > kC2Spin) { alive = false; break; }
+      }
+      if (!alive) break;
+      const uint32_t x = (v & 15u) << 4 | cand;
+      // ---- HCOMP for the candidates (all 64 lanes run it: four copies of each candidate)
+      uint32_t sa = x, sb = hb, sc = hc, sd = hd, sf = hf;
+      uint32_t wi = 0, wv = 0, wn = 0, hs[NH], wmask = 0;
+#pragma unroll
+      for (uint32_t d = 0; d < NH; ++d) hs[d] = 0;
+      const SpecM sm{(lds_u8_p)lds_off(S.mreg), &wi, &wv, &wn};
+      const SpecH<NH> sh{(lds_u32_p)lds_off(S.hreg), hs, &wmask};
+      if constexpr (SP::id == 1) (void)zh_native_hcomp_min(sa, sb, sc, sd, sf, x, sm, (1u << SP::hm) - 1u, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
+      else (void)zh_native_hcomp_mid(sa, sb, sc, sd, sf, x, sm, (1u << SP::hm) - 1u, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
+      if (grp == 0) {
+#pragma unroll
+        for (uint32_t d = 0; d < NH; ++d) S.hspec[d][cand] = (uint32_t)sh[d];
+      }
+      // ---- rows of the first nibble of the next byte (c8 = 1): Predictor.find's three candidates per component
+      v4u rr[2][3];
+#pragma unroll
+      for (uint32_t r = 0; r < 2; ++r) {
+        uint32_t hval = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < NH; ++d) if ((u_comp[r] & (NH - 1u)) == d) hval = (uint32_t)sh[d];
+        const uint32_t cxt = hval + 16u;
+        const uint32_t h0 = (cxt * 16u) & (u_mask[r] - 15u);
+        const uint32_t vo = u_on[r] ? u_hto[r] + h0 : kOob;
+        rr[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
+        rr[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo ^ 16u, 0, 0);
+        rr[r][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo ^ 32u, 0, 0);
+      }
+      // ---- mixer rows for c8 = 1: weights grp, grp+4, grp+8, grp+12 of the row of candidate `cand`
+      uint32_t mwv[2][4];
+#pragma unroll
+      for (uint32_t q = 0; q < SP::nmix; ++q) {
+        uint32_t hq = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < NH; ++d) if ((SP::mix_lane[q] & (NH - 1u)) == d) hq = (uint32_t)sh[d];
+        const ZhComp &mc = M->comp[SP::mix_lane[q]];
+        const uint32_t row = mx_base[q] + ((hq + (1u & (uint32_t)mc.arg[4])) & mx_size1[q]) * (SP::mix_m[q] * 4u);
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) {
+          const uint32_t jj = grp + 4u * t;
+          mwv[q][t] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, jj < SP::mix_m[q] ? row + jj * 4u : kOob, 0, 0);
+        }
+      }
+#pragma unroll
+      for (uint32_t r = 0; r < 2; ++r) {
+        if (u_on[r]) {
+#pragma unroll
+          for (uint32_t k = 0; k < 3; ++k) *(lds_u4_p)lds_off(&S.rowst[grp + 4u * r][k][cand]) = rr[r][k];
+        }
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < SP::nmix; ++q)
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) S.mixst[q][cand][grp + 4u * t] = mwv[q][t];
+      asm volatile("" ::: "memory");
+      c2_put0(&S.mb_ready, seq);
+      // ---- the byte: commit its candidate
+      sp = 0;
+      while (((v = c2_ld(&S.mb_byte)) >> 8) != seq) {
+        if (c2_ld(&S.mb_cmd) != seen_cmd || ++sp > kC2Spin) { alive = false; break; }
+      }
+      if (!alive) break;
+      const uint32_t lo = v & 15u;
+      ha = rdlane(sa, lo); hb = rdlane(sb, lo); hc = rdlane(sc, lo); hd = rdlane(sd, lo); hf = rdlane(sf, lo);
+      const uint32_t cwi = rdlane(wi, lo), cwv = rdlane(wv, lo), cwn = rdlane(wn, lo);
+      if (cwn && lane == 0) S.mreg[cwi] = (uint8_t)cwv;
+      if (lane < NH) { const uint32_t hv_ = S.hspec[lane][lo]; S.hreg[lane] = hv_; }
+      ++seq;
+    }
+  }
+}
+
 // Diagnostic build (PROF): cycles per stage, summed per block into L.debug[0..7].  Stamps wait for LDS/scalar results
 // only (global memory stays in flight, as in the real kernel).
 #define C2_STAMP(i)                                                                                  \
@@ -174,25 +363,30 @@ constexpr uint32_t kOob = 0x80000000u;        // buffer offset beyond every aren
     }                                                                                                \
   } while (0)
 
-template <class SP, bool PROF>
-__device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) {
-  uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+__device__ __forceinline__ void c2_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }   // one wave: no barrier
+
+template <class SP, bool PROF, bool HELP, class LDS>
+__device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
+  uint64_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tprev = 0;
-  const uint32_t lane = threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const bool wave_a = (threadIdx.x >> 6) == 0;
   constexpr uint64_t kII = SP::icm | SP::isse;
   const bool l_isse = (SP::isse >> lane) & 1, l_ii = (kII >> lane) & 1;
   const bool l_match = SP::match_lane >= 0 && lane == (uint32_t)SP::match_lane;
 
-  {  // model-independent tables -> LDS (ZhTables: squash, stretch, dt, dt2k, ns)
+  if (wave_a) {  // model-independent tables -> LDS (ZhTables: squash, stretch, dt, dt2k, ns)
     const ZhTables *T = L.tables;
     for (uint32_t i = lane; i < 32768 / 8; i += 64) reinterpret_cast<uint4 *>(S.stretch)[i] = reinterpret_cast<const uint4 *>(T->stretch)[i];
     for (uint32_t i = lane; i < 4096 / 8; i += 64) reinterpret_cast<uint4 *>(S.squash)[i] = reinterpret_cast<const uint4 *>(T->squash)[i];
     for (uint32_t i = lane; i < 1024 / 4; i += 64) reinterpret_cast<uint4 *>(S.dt)[i] = reinterpret_cast<const uint4 *>(T->dt)[i];
     for (uint32_t i = lane; i < 256 / 4; i += 64) reinterpret_cast<uint4 *>(S.dt2k)[i] = reinterpret_cast<const uint4 *>(T->dt2k)[i];
     for (uint32_t i = lane; i < 1024 / 16; i += 64) reinterpret_cast<uint4 *>(S.ns)[i] = reinterpret_cast<const uint4 *>(T->ns)[i];
-    if (lane == 0) S.zrow = v4u_{0, 0, 0, 0};
+    if (lane == 0) { S.zrow = v4u_{0, 0, 0, 0}; S.mb_cmd = 0; S.mb_ack = 0; S.mb_nib = 0; S.mb_byte = 0; S.mb_ready = 0; }
   }
-  __syncthreads();
+  __syncthreads();                                       // the only workgroup barrier of the kernel
+  if constexpr (HELP) { if (!wave_a) { c2_helper<SP>(L, S, lane); return; } }
+  uint32_t cmd_seq = 0;                                  // commands issued to the helper wave
 
   uint8_t *slot_mem = L.arena + (uint64_t)blockIdx.x * L.arena_stride;
   const lds_i16_p lds_stretch = (lds_i16_p)lds_off(S.stretch);
@@ -278,7 +472,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
       S.lent[lane] = v2u{0, 0};
       S.lsink[lane] = 0;
     }
-    __syncthreads();
+    c2_wave_sync();
 
     // ---- per-lane constants
     const ZhComp *mycp = &M->comp[lane < SP::n ? lane : 0];
@@ -356,7 +550,18 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
     out_room(ob);
     Sink &sink = S.sink;
     sink.out = ob.base; sink.cap = ob.cap; sink.len = 0;
-    __syncthreads();
+    c2_wave_sync();
+    uint32_t bseq = 1;                                  // bytes of this block decoded so far + 1 (the helper wave's clock)
+    bool helper_ok = true;
+    if (HELP) {                                         // wake the helper wave for this block (tables and VM memories are ready)
+      if (lane == 0) { S.mb_model = model_i; S.mb_nib = 0; S.mb_byte = 0; S.mb_ready = 0; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      ++cmd_seq;
+      c2_put0(&S.mb_cmd, cmd_seq << 2 | kC2New);
+      uint32_t sp = 0;
+      while (c2_ld(&S.mb_ack) != (cmd_seq << 2 | kC2New)) { if (++sp > kC2Spin) { helper_ok = false; break; } }
+    }
+    if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }   // stage 0 also takes what lies between stamps
     InBuf in;
     in.stream = L.in; in.total = L.in_total; in.cbase = 0; in.k = 0; in.avail = 0; in.cur = 0;
 
@@ -372,6 +577,61 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
     // MATCH (Predictor.cs:273-287, 382-411): the lane's Component fields
     uint32_t m_len = 0, m_ptr = 0, m_limit = 0, m_byte = 0;
     int pm0 = 0, pm1 = 0;                               // stretch of -+dt2k[len] for this byte; 0 once the match has failed
+    // What the byte boundary will want from HBM is requested half a byte early (match_prefetch, at bit 4): cm_pre is
+    // the hash-index entry of the current h[i] (read when h[i] was set: nothing else writes the index before the next
+    // boundary), va/vb the first 64 byte pairs of the candidate's verification, mbn/mbc the byte predicted by the
+    // candidate / by the match that continues.  The one byte these cannot hold — the one being decoded — is put in at
+    // the boundary.
+    uint32_t cm_pre = 0, va_pre = 0, vb_pre = 0, mbn_pre = 0, mbc_pre = 0;
+    auto match_prefetch = [&]() __attribute__((always_inline)) {
+      const uint32_t ml = (uint32_t)(SP::match_lane >= 0 ? SP::match_lane : 0);
+      const uint32_t msk = rdlane(ht_mask, ml), base = rdlane(hto, ml);
+      const uint32_t lim = (rdlane(m_limit, ml) + 1u) & msk;                 // m_limit once this byte is stored
+      const uint32_t off = lim - rdlane(cm_pre, ml);                        // the candidate's distance, should the byte end unmatched
+      va_pre = __builtin_amdgcn_raw_buffer_load_b8(rsrc, base + ((lim - lane - 1u) & msk), 0, 0);
+      vb_pre = __builtin_amdgcn_raw_buffer_load_b8(rsrc, base + ((lim - lane - off - 1u) & msk), 0, 0);
+      mbn_pre = __builtin_amdgcn_raw_buffer_load_b8(rsrc, l_match ? base + ((lim - off) & msk) : kOob, 0, 0);
+      mbc_pre = __builtin_amdgcn_raw_buffer_load_b8(rsrc, l_match ? base + ((lim - m_ptr) & msk) : kOob, 0, 0);
+    };
+    // Predictor.update's MATCH part at the byte boundary (Predictor.cs:391-410); c is already in the history and the
+    // hash index, m_limit advanced
+    auto match_boundary = [&](uint32_t cb) __attribute__((always_inline)) {
+      uint32_t need = 0;
+      if (l_match) {
+        if (m_len == 0) {
+          m_ptr = m_limit - cm_pre;
+          need = (m_ptr & ht_mask) != 0;
+        } else m_len += m_len < 255;
+      }
+      const bool verify = __ballot(need != 0) != 0;
+      if (verify) {                                      // verify the candidate with the whole wave (Predictor.cs:403-405)
+        const uint32_t ml = (uint32_t)SP::match_lane;
+        const uint32_t lim = rdlane(m_limit, ml), off = rdlane(m_ptr, ml), msk = rdlane(ht_mask, ml);
+        const uint32_t a = lane == 0 ? cb : (va_pre & 255u);
+        const uint32_t b = ((lane + off) & msk) == 0 ? cb : (vb_pre & 255u);
+        uint64_t mism = __ballot(a != b);
+        uint32_t len = 64;
+        if (mism) len = (uint32_t)__builtin_ctzll(mism);
+        else {
+          const uint8_t *hp = slot_mem + rdlane(hto, ml);
+          for (uint32_t base = 64; base < 256; base += 64) {
+            const uint32_t t = base + lane;
+            const bool eq = t < 255 && hp[(lim - t - 1) & msk] == hp[(lim - t - off - 1) & msk];
+            mism = __ballot(!eq);
+            if (mism) { len += (uint32_t)__builtin_ctzll(mism); break; }
+            len += 64;
+          }
+        }
+        if (l_match) {
+          m_len = len > 255 ? 255 : len;
+          m_byte = ((off - 1u) & msk) == 0 ? cb : (mbn_pre & 255u);
+        }
+      } else if (l_match && m_len) m_byte = ((m_ptr - 1u) & ht_mask) == 0 ? cb : (mbc_pre & 255u);
+      const int dk = S.dt2k[l_match ? m_len : 0];
+      pm0 = S.stretch[dk & 32767];
+      pm1 = S.stretch[(-dk) & 32767];
+      if (!l_match || m_len == 0) { pm0 = 0; pm1 = 0; }
+    };
 
     // Hash rows of the nibble that starts now (c8 == 1 or 16 <= c8 < 32), Predictor.find (Predictor.cs:550-567).
     // issue: the three candidate rows are requested; `old` is the row this lane holds (just evicted, maybe still in
@@ -386,9 +646,14 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
       pr.r1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo ^ 16u, 0, 0);
       pr.r2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo ^ 32u, 0, 0);
     };
-    auto rows_finish = [&](Probe &pr, const v4u &old, uint32_t old_off, bool old_valid) __attribute__((always_inline)) {
+    // (olda, oldb: rows this wave evicted after the probe's loads may have been issued — by itself or by the helper wave)
+    auto rows_finish2 = [&](const Probe &pr, const v4u &olda, uint32_t olda_off, bool olda_valid, const v4u &old, uint32_t old_off,
+                            bool old_valid) __attribute__((always_inline)) {
       const uint32_t h0 = pr.h0, h1 = h0 ^ 16u, h2 = h0 ^ 32u;
       v4u r0 = pr.r0, r1 = pr.r1, r2 = pr.r2;
+      if (olda_valid && olda_off == h0) r0 = olda;
+      if (olda_valid && olda_off == h1) r1 = olda;
+      if (olda_valid && olda_off == h2) r2 = olda;
       if (old_valid && old_off == h0) r0 = old;
       if (old_valid && old_off == h1) r1 = old;
       if (old_valid && old_off == h2) r2 = old;
@@ -401,6 +666,9 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
       const v4u row = m0 ? r0 : m1 ? r1 : m2 ? r2 : fresh;
       *(lds_u4_p)lds_off(&S.slot[lane]) = row;           // lanes without a hash table never read their slot
       rowoff = sel; rowvalid = true;
+    };
+    auto rows_finish = [&](const Probe &pr, const v4u &old, uint32_t old_off, bool old_valid) __attribute__((always_inline)) {
+      rows_finish2(pr, old, 0u, false, old, old_off, old_valid);
     };
     // write the row of the finished nibble back (fire and forget) and hand its content to the caller
     auto row_evict = [&](v4u &old, uint32_t &old_off, bool &old_valid) __attribute__((always_inline)) {
@@ -487,15 +755,17 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
           // ======== one bit.  NODE = position in the nibble (0..3); the node index is hm (1, 2-3, 4-7, 8-15).
           uint32_t hm = 1;
           uint32_t pairS = 0;                            // bit histories of nodes 2hm, 2hm+1
+          C2_STAMP(10);
           Probe spec[4];                                 // candidate rows of the second nibble
+          v4u old1 = {0, 0, 0, 0}; uint32_t old1_off = 0; bool old1_valid = false;   // the first nibble's row as it was evicted
           l0_direct();
 #pragma unroll
           for (int bit = 0; bit < 8; ++bit) {
             const bool pre_ii = (bit & 3) != 3;          // the next bit stays in this nibble: fetch both of its nodes
             const bool pre_mx = bit != 7;                // the next bit stays in this byte: fetch both of its mixer rows
             hm = uni(hm); c8 = uni(c8);
-            if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
             // ---- (a) requests for the NEXT bit, both ways
+            if (SP::match_lane >= 0 && bit == 4) match_prefetch();
             uint32_t ea0 = 0, ea1 = 0;
             v2u e0 = {0, 0}, e1 = e0;
             if (pre_ii) pairS = *(lds_u16_p)(rrow + 2u * hm);
@@ -606,7 +876,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
             for (uint32_t q = 0; q < SP::nmix; ++q) {     // MIX (Predictor.cs:427-439): error from the mixer lane
               const int eq = __mul24((int)rdlane((uint32_t)e, SP::mix_lane[q]), mx_rate[q]) >> 4;
               const int nmw = med3i(mw[q] + ((__mul24(eq, p) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
-              __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw, rsrc, vo_mix[q], mrow[q], 0);
+              __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw, rsrc, vo_mix[q], uni(mrow[q]), 0);
             }
             if constexpr (SP::id == 3) {
               auto mix2_train = [&](int w, int rate, uint32_t ln, int pj_, int pk_) __attribute__((always_inline)) -> int {   // Predictor.cs:414-426
@@ -644,7 +914,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
             c8 = c8 * 2u + y;
             if (pre_mx) {
 #pragma unroll
-              for (uint32_t q = 0; q < SP::nmix; ++q) { mw[q] = y ? mwc1[q] : mwc0[q]; mrow[q] = y ? mrow1[q] : mrow0[q]; }
+              for (uint32_t q = 0; q < SP::nmix; ++q) { mw[q] = y ? mwc1[q] : mwc0[q]; mrow[q] = uni(y ? mrow1[q] : mrow0[q]); }
             }
             if (SP::has_tail && pre_mx) {
               row18 = row18n; row20 = row20n;
@@ -662,6 +932,14 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
               // ---- second nibble (Predictor.cs:267-270: c8 & 0xf0 == 16): new rows, requested two bits ago
               v4u old; uint32_t old_off; bool old_valid;
               row_evict(old, old_off, old_valid);
+              old1 = old; old1_off = old_off; old1_valid = old_valid;
+              if (HELP) {
+                // The helper wave now prepares the next byte for the 16 values this one can still take.  Everything this
+                // wave has stored so far has reached memory before the helper is told (vmcnt(0)); what it stores later
+                // that the helper's loads could miss — the two hash rows of this byte — is patched in from the copies
+                // kept here (old1, and the second nibble's row at the byte's end).
+                c2_put0(&S.mb_nib, bseq << 8 | (c8 & 15u));
+              }
               switch (c8 & 3u) {                         // wave-uniform: four copies of the selection code, no data selects
                 case 0: rows_finish(spec[0], old, old_off, old_valid); break;
                 case 1: rows_finish(spec[1], old, old_off, old_valid); break;
@@ -679,21 +957,58 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
 #pragma unroll
               for (uint32_t k = 0; k < 4; ++k) rows_issue(c8 * 4u + k, spec[k]);
             }
+            C2_STAMP(8);
           }
           if (UNLIKELY(err | bad)) { status = err ? -(int)err : ZH_E_CORRUPT; break; }
           c = (int)(c8 - 256);
 
           // ---- byte boundary: MATCH (Predictor.cs:391-410), HCOMP, h[], rows of the next byte
-          if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
           {
-            uint32_t cmv = 0;
             if (l_match) {                               // still with the h[i] of the byte just coded (update0 runs before z.run)
               (slot_mem + hto)[m_limit & ht_mask] = (uint8_t)c;
               m_limit = (m_limit + 1) & ht_mask;
               uint32_t *cm = reinterpret_cast<uint32_t *>(slot_mem + cmo);
-              cmv = cm[hv & cm_mask];
-              cm[hv & cm_mask] = m_limit;
+              cm[hv & cm_mask] = m_limit;                // (its old value: cm_pre)
             }
+            if (HELP) {
+              // ---- two-wave form: the helper wave ran HCOMP for this byte's value among 16 and staged what follows
+              c2_put0(&S.mb_byte, bseq << 8 | (uint32_t)c);
+              uint32_t sp = 0;
+              while (helper_ok && c2_ld(&S.mb_ready) != bseq) { if (++sp > kC2Spin) helper_ok = false; }
+              if (!helper_ok) { status = -24; break; }       // ZPAQHIP_E_HIP: the helper wavefront stopped answering (cannot happen by design)
+              asm volatile("" ::: "memory");
+              const uint32_t lo = (uint32_t)c & 15u;
+              hv = S.hspec[lane & ((1u << SP::hh) - 1u)][lo];
+              C2_STAMP(5);
+              v4u old; uint32_t old_off; bool old_valid;
+              row_evict(old, old_off, old_valid);
+              Probe pr;
+              {
+                const uint32_t cxt = hv + 16u;
+                pr.chk = (cxt >> sizebits2) & 255;
+                pr.h0 = (cxt * 16u) & (ht_mask - 15u);
+                const uint32_t un = unit < (uint32_t)kSpecUnits ? unit : 0u;
+                pr.r0 = *(lds_u4_p)lds_off(&S.rowst[un][0][lo]);
+                pr.r1 = *(lds_u4_p)lds_off(&S.rowst[un][1][lo]);
+                pr.r2 = *(lds_u4_p)lds_off(&S.rowst[un][2][lo]);
+              }
+#pragma unroll
+              for (uint32_t q = 0; q < SP::nmix; ++q) {
+                mx_h[q] = rdlane(hv, SP::mix_lane[q]);
+                mrow[q] = mix_row(q, mx_h[q], 1u);
+                const uint32_t jj = lane - SP::mix_j0[q];
+                mw[q] = jj < SP::mix_m[q] ? (int)S.mixst[q][lo][jj & 15u] : 0;
+              }
+              ++bseq;
+              if (SP::match_lane >= 0) {
+                match_boundary((uint32_t)c);
+                if (l_match) cm_pre = reinterpret_cast<uint32_t *>(slot_mem + cmo)[hv & cm_mask];
+              }
+              C2_STAMP(6);
+              rows_finish2(pr, old1, old1_off, old1_valid, old, old_off, old_valid);
+              asm volatile("" ::: "memory");
+              C2_STAMP(7);
+            } else {
             int rc;
             switch (hnative) {
               case ZH_NATIVE_HCOMP_MIN: rc = zh_native_hcomp_min(ha, hb, hc, hd, hf, (uint32_t)c, reg_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
@@ -721,41 +1036,14 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
               a19i = 1u; w19 = uni((uint32_t)S.a19[1]);
             }
             if (SP::match_lane >= 0) {
-              uint32_t need = 0;
-              if (l_match) {
-                if (m_len == 0) {
-                  m_ptr = m_limit - cmv;
-                  need = (m_ptr & ht_mask) != 0;
-                } else m_len += m_len < 255;
-              }
-              uint32_t mb_new = 0;
-              const bool verify = __ballot(need != 0) != 0;
-              if (verify) {                              // verify the candidate with the whole wave (Predictor.cs:403-405)
-                const uint32_t ml = (uint32_t)SP::match_lane;
-                const uint32_t lim = rdlane(m_limit, ml), off = rdlane(m_ptr, ml), msk = rdlane(ht_mask, ml);
-                const uint8_t *hp = slot_mem + rdlane(hto, ml);
-                mb_new = hp[(lim - off) & msk];          // the byte the candidate predicts: same round trip as the comparison
-                uint32_t len = 0;
-                for (uint32_t base = 0; base < 256; base += 64) {
-                  const uint32_t t = base + lane;
-                  const bool eq = t < 255 && hp[(lim - t - 1) & msk] == hp[(lim - t - off - 1) & msk];
-                  const uint64_t mism = __ballot(!eq);
-                  if (mism) { len += (uint32_t)__builtin_ctzll(mism); break; }
-                  len += 64;
-                }
-                if (l_match) m_len = len > 255 ? 255 : len;
-              }
-              if (verify) { if (l_match) m_byte = mb_new; }
-              else if (l_match && m_len) m_byte = (slot_mem + hto)[(m_limit - m_ptr) & ht_mask];
-              const int dk = S.dt2k[l_match ? m_len : 0];
-              pm0 = S.stretch[dk & 32767];
-              pm1 = S.stretch[(-dk) & 32767];
-              if (!l_match || m_len == 0) { pm0 = 0; pm1 = 0; }
+              match_boundary((uint32_t)c);
+              if (l_match) cm_pre = reinterpret_cast<uint32_t *>(slot_mem + cmo)[hv & cm_mask];
             }
             C2_STAMP(6);
             rows_finish(pr, old, old_off, old_valid);
             asm volatile("" ::: "memory");
             C2_STAMP(7);
+            }
           }
         }
 
@@ -786,13 +1074,14 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
           if (c < 0) { status = ZH_E_PP_EOS; break; }
           pzbuf[pp_len] = (uint8_t)c;
           if ((int)++pp_len == pp_hsize) {
-            __syncthreads();
+            c2_wave_sync();
             pz.prog = pzbuf; pz.len = pp_len;
             pz.a = pz.b = pz.c = pz.d = pz.f = 0;
             pnative = p_lds ? uni(zh_native_lookup(pzbuf, pp_len)) : 0;
             pp_state = 5;
           }
         }
+        C2_STAMP(9);
         if (c < 0) break;
       }
 
@@ -809,17 +1098,20 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, C2Lds &S) 
       }
     }
     if (PROF && lane == 0 && L.debug)
-      for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
-    __syncthreads();
+      for (int i = 0; i < 12; ++i) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
+    if (HELP) { ++cmd_seq; c2_put0(&S.mb_cmd, cmd_seq << 2 | kC2End); }     // the helper wave waits for the next block
+    c2_wave_sync();
   }
+  if (HELP) { ++cmd_seq; c2_put0(&S.mb_cmd, cmd_seq << 2 | kC2Exit); }
 }
 
 }  // namespace
 
 #define ZH_CHAIN2_KERNEL(name, spec, prof)                                             \
-  extern "C" __global__ __launch_bounds__(64) void name(ZhLaunch L) {                  \
-    __shared__ C2Lds S;                                                                \
-    decode_chain2_body<spec, prof>(L, S);                                              \
+  extern "C" __global__ __launch_bounds__(spec::helper ? 128 : 64) void name(ZhLaunch L) { \
+    typedef C2LdsT<spec::has_tail, spec::helper> Lds;                                  \
+    __shared__ Lds S;                                                                  \
+    decode_chain2_body<spec, prof, spec::helper, Lds>(L, S);                           \
   }
 ZH_CHAIN2_KERNEL(zh_decode_c2_min, C2Min, false)
 ZH_CHAIN2_KERNEL(zh_decode_c2_mid, C2Mid, false)
@@ -832,7 +1124,7 @@ extern "C" hipError_t zh_launch_chain2(const ZhLaunch *L, uint32_t grid, hipStre
   void (*k)(ZhLaunch) = spec == 1 ? zh_decode_c2_min : spec == 2 ? zh_decode_c2_mid : spec == 3 ? zh_decode_c2_max : nullptr;
   if (prof && spec >= 2) k = spec == 2 ? zh_decode_c2_mid_prof : zh_decode_c2_max_prof;
   if (!k) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, stream, *L);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(spec == 3 ? 64 : 128), 0, stream, *L);     // min / mid: decoder wave + helper wave
   return hipGetLastError();
 }
 extern "C" int zh_chain2_has(uint32_t spec) { return spec >= 1 && spec <= 3; }

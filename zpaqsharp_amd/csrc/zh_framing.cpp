@@ -429,6 +429,10 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
     const uint32_t native = zh_native_lookup(hdr + cp, m.hcomp_len);     // native HCOMP id or 0
     // zh_chain2.hip's max code relies on what the built-in HCOMP leaves in h[17..21] (zeros, and an even h[20])
     if (spec == 3 && native != ZH_NATIVE_HCOMP_MAX) spec = 0;
+    // ... its min / mid code hands HCOMP to a helper wavefront that runs the translated program of that model for 16
+    // candidate bytes at once, with H and M of exactly the built-in sizes
+    if (spec == 1 && (native != ZH_NATIVE_HCOMP_MIN || m.hh != 1 || m.hm != 2)) spec = 0;
+    if (spec == 2 && (native != ZH_NATIVE_HCOMP_MID || m.hh != 3 || m.hm != 3)) spec = 0;
     // ... and it keeps H in 256 LDS words and M in one or two vector registers (256 / 512 bytes)
     if (spec && (m.hh > 8 || m.hm > (spec == 3 ? 9u : 8u))) spec = 0;
     m.kind += spec;
