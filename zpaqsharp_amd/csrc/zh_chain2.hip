@@ -82,7 +82,7 @@ struct alignas(16) C2LdsT {
   int16_t stretch[32768];                     // at LDS offset 0 of this struct: see lds_stretch()
   uint16_t squash[4096];
   int32_t dt[1024];
-  int32_t dt2k[256];
+  uint32_t pm01[256];                         // MATCH: stretch(dt2k[len]) | stretch(-dt2k[len]) << 16 (Predictor.cs:273-287), [0] = 0
   uint8_t ns[1024];
   v2u_ ent[kEntUnits][256];                  // {A, B}: ISSE {w0, w1} (Predictor.cs:148-152), ICM {cm, stretch(cm >> 8)}
   v4u_ slot[64];                             // per-lane hash row of the current nibble
@@ -200,12 +200,35 @@ struct SpecH {
 template <> struct ZhUniform<SpecM> { static constexpr bool value = false; };
 namespace {
 
-__device__ __forceinline__ uint32_t c2_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t c2_ld(const uint32_t *p) {      // a mailbox word: one value for the wave (scalar control flow)
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
 // one dword into LDS from lane 0 (all lanes enabled around it).  The LDS unit serves a CU's requests in arrival order and a
 // wave issues them in program order, so data written before this flag is seen by whoever sees the flag (as in zh_cm.hip).
 __device__ __forceinline__ void c2_put0(const uint32_t *where, uint32_t val) {
   const uint32_t addr = (uint32_t)(uintptr_t)where;
   asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(val) : "memory");
+}
+// Spins (on the scalar unit) until the mailbox word equals `want`; false after kC2Spin polls: nothing may hang the GPU.
+__device__ __forceinline__ bool c2_wait(const uint32_t *where, uint32_t want) {
+  const uint32_t addr = (uint32_t)(uintptr_t)where;
+  uint32_t left = 1u << 26, got, tmp;
+  want = (uint32_t)__builtin_amdgcn_readfirstlane((int)want);
+  asm volatile(
+      ".Lc2w_%=:\n\t"
+      "ds_read_b32 %[t], %[a]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_readfirstlane_b32 %[g], %[t]\n\t"
+      "s_cmp_eq_u32 %[g], %[w]\n\t"
+      "s_cbranch_scc1 .Lc2d_%=\n\t"
+      "s_sub_u32 %[l], %[l], 1\n\t"
+      "s_cmp_lg_u32 %[l], 0\n\t"
+      "s_cbranch_scc1 .Lc2w_%=\n"
+      ".Lc2d_%=:"
+      : [t] "=&v"(tmp), [g] "=&s"(got), [l] "+s"(left)
+      : [a] "v"(addr), [w] "s"(want)
+      : "memory", "scc");
+  return left != 0;
 }
 enum : uint32_t { kC2New = 1, kC2End = 2, kC2Exit = 3 };
 constexpr uint32_t kC2Spin = 1u << 26;            // bounded waits: nothing may hang the GPU
@@ -380,13 +403,18 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     for (uint32_t i = lane; i < 32768 / 8; i += 64) reinterpret_cast<uint4 *>(S.stretch)[i] = reinterpret_cast<const uint4 *>(T->stretch)[i];
     for (uint32_t i = lane; i < 4096 / 8; i += 64) reinterpret_cast<uint4 *>(S.squash)[i] = reinterpret_cast<const uint4 *>(T->squash)[i];
     for (uint32_t i = lane; i < 1024 / 4; i += 64) reinterpret_cast<uint4 *>(S.dt)[i] = reinterpret_cast<const uint4 *>(T->dt)[i];
-    for (uint32_t i = lane; i < 256 / 4; i += 64) reinterpret_cast<uint4 *>(S.dt2k)[i] = reinterpret_cast<const uint4 *>(T->dt2k)[i];
     for (uint32_t i = lane; i < 1024 / 16; i += 64) reinterpret_cast<uint4 *>(S.ns)[i] = reinterpret_cast<const uint4 *>(T->ns)[i];
     if (lane == 0) { S.zrow = v4u_{0, 0, 0, 0}; S.mb_cmd = 0; S.mb_ack = 0; S.mb_nib = 0; S.mb_byte = 0; S.mb_ready = 0; }
   }
   __syncthreads();                                       // the only workgroup barrier of the kernel
   if constexpr (HELP) { if (!wave_a) { c2_helper<SP>(L, S, lane); return; } }
   uint32_t cmd_seq = 0;                                  // commands issued to the helper wave
+  for (uint32_t i = lane; i < 256; i += 64) {            // the two predictions of a match of length i
+    const int dk = L.tables->dt2k[i];
+    const uint32_t lo = (uint16_t)S.stretch[dk & 32767], hi = (uint16_t)S.stretch[(-dk) & 32767];
+    S.pm01[i] = i ? lo | hi << 16 : 0u;
+  }
+  c2_wave_sync();
 
   uint8_t *slot_mem = L.arena + (uint64_t)blockIdx.x * L.arena_stride;
   const lds_i16_p lds_stretch = (lds_i16_p)lds_off(S.stretch);
@@ -558,8 +586,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       ++cmd_seq;
       c2_put0(&S.mb_cmd, cmd_seq << 2 | kC2New);
-      uint32_t sp = 0;
-      while (c2_ld(&S.mb_ack) != (cmd_seq << 2 | kC2New)) { if (++sp > kC2Spin) { helper_ok = false; break; } }
+      helper_ok = c2_wait(&S.mb_ack, cmd_seq << 2 | kC2New);
     }
     if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }   // stage 0 also takes what lies between stamps
     InBuf in;
@@ -596,22 +623,19 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     // Predictor.update's MATCH part at the byte boundary (Predictor.cs:391-410); c is already in the history and the
     // hash index, m_limit advanced
     auto match_boundary = [&](uint32_t cb) __attribute__((always_inline)) {
-      uint32_t need = 0;
-      if (l_match) {
-        if (m_len == 0) {
-          m_ptr = m_limit - cm_pre;
-          need = (m_ptr & ht_mask) != 0;
-        } else m_len += m_len < 255;
-      }
-      const bool verify = __ballot(need != 0) != 0;
-      if (verify) {                                      // verify the candidate with the whole wave (Predictor.cs:403-405)
+      const bool zero = m_len == 0;
+      const uint32_t nptr = m_limit - cm_pre;
+      const bool need = l_match && zero && (nptr & ht_mask) != 0;
+      m_ptr = (l_match && zero) ? nptr : m_ptr;
+      m_len = (l_match && !zero && m_len < 255) ? m_len + 1 : m_len;
+      if (__ballot(need) != 0) {                         // verify the candidate with the whole wave (Predictor.cs:403-405)
         const uint32_t ml = (uint32_t)SP::match_lane;
         const uint32_t lim = rdlane(m_limit, ml), off = rdlane(m_ptr, ml), msk = rdlane(ht_mask, ml);
         const uint32_t a = lane == 0 ? cb : (va_pre & 255u);
         const uint32_t b = ((lane + off) & msk) == 0 ? cb : (vb_pre & 255u);
         uint64_t mism = __ballot(a != b);
         uint32_t len = 64;
-        if (mism) len = (uint32_t)__builtin_ctzll(mism);
+        if (LIKELY(mism != 0)) len = (uint32_t)__builtin_ctzll(mism);
         else {
           const uint8_t *hp = slot_mem + rdlane(hto, ml);
           for (uint32_t base = 64; base < 256; base += 64) {
@@ -622,15 +646,15 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             len += 64;
           }
         }
-        if (l_match) {
-          m_len = len > 255 ? 255 : len;
-          m_byte = ((off - 1u) & msk) == 0 ? cb : (mbn_pre & 255u);
-        }
-      } else if (l_match && m_len) m_byte = ((m_ptr - 1u) & ht_mask) == 0 ? cb : (mbc_pre & 255u);
-      const int dk = S.dt2k[l_match ? m_len : 0];
-      pm0 = S.stretch[dk & 32767];
-      pm1 = S.stretch[(-dk) & 32767];
-      if (!l_match || m_len == 0) { pm0 = 0; pm1 = 0; }
+        const uint32_t nl = len > 255 ? 255 : len;
+        m_len = l_match ? nl : m_len;
+        m_byte = l_match ? (((off - 1u) & msk) == 0 ? cb : (mbn_pre & 255u)) : m_byte;
+      } else {
+        const uint32_t cont = ((m_ptr - 1u) & ht_mask) == 0 ? cb : (mbc_pre & 255u);
+        m_byte = (l_match && m_len) ? cont : m_byte;
+      }
+      const uint32_t pw = *(lds_u32_p)(lds_off(S.pm01) + m_len * 4u);      // m_len stays 0 in the other lanes
+      pm0 = (int)(int16_t)(pw & 0xffffu); pm1 = (int)pw >> 16;
     };
 
     // Hash rows of the nibble that starts now (c8 == 1 or 16 <= c8 < 32), Predictor.find (Predictor.cs:550-567).
@@ -683,10 +707,17 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
       const v2u e = *(lds_u2_p)ea;
       eA = e.x; eB = e.y;
     };
-    auto mix_row = [&](uint32_t q, uint32_t hq, uint32_t c8) __attribute__((always_inline)) -> uint32_t {
-      return uni(mx_base[q] + ((uni(hq) + (c8 & mx_cmask[q])) & mx_size1[q]) * mx_m4[q]);   // pinned to the scalar unit
+    // Mixer rows (Predictor.cs:302-316: row (h[i] + (c8 & mask)) & (size - 1)).  A block comes here only with the model's
+    // own COMP list and HCOMP (zh_framing.cpp), whose mixer contexts are multiples of 256 with mask 255: the 255 rows of
+    // a byte are consecutive, mx_rb + c8 * row bytes.
+    uint32_t mx_h[2] = {0, 0}, mx_rb[2] = {0, 0};        // h[] of the mixer components, arena offset of their row 0 (scalar)
+    auto mix_set = [&](uint32_t q, uint32_t hq) __attribute__((always_inline)) {
+      mx_h[q] = uni(hq);
+      mx_rb[q] = uni(mx_base[q] + (mx_h[q] & mx_size1[q] & ~255u) * mx_m4[q]);
     };
-    uint32_t mx_h[2] = {0, 0};                           // h[] of the mixer components (scalar)
+    auto mix_row = [&](uint32_t q, uint32_t c8) __attribute__((always_inline)) -> uint32_t {
+      return uni(mx_rb[q] + (c8 & 255u) * (SP::mix_m[q] * 4u));          // pinned to the scalar unit
+    };
     // ---- tail of the max model (components 17-21); the host routes a block here only with the built-in HCOMP, which
     // leaves h[17] = h[18] = h[19] = h[21] = 0 and h[20] = byte << 9 (even), so the two rows a bit can lead to are one
     // aligned row pair of each SSE table
@@ -728,7 +759,8 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
         rows_finish(pr, v4u{0, 0, 0, 0}, 0u, false);
 #pragma unroll
         for (uint32_t q = 0; q < SP::nmix; ++q) {
-          mrow[q] = mix_row(q, 0u, 1u);
+          mix_set(q, 0u);
+          mrow[q] = mix_row(q, 1u);
           mw[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow[q], 0);
         }
         if (SP::has_tail) { row18 = row18_load(1u); row20 = row20_load(1u); a19i = 1u; w19 = uni((uint32_t)S.a19[1]); }
@@ -774,8 +806,8 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             if (pre_mx) {
 #pragma unroll
               for (uint32_t q = 0; q < SP::nmix; ++q) {
-                mrow0[q] = mix_row(q, mx_h[q], c8 * 2u);
-                mrow1[q] = mix_row(q, mx_h[q], c8 * 2u + 1u);
+                mrow0[q] = mix_row(q, c8 * 2u);
+                mrow1[q] = mrow0[q] + SP::mix_m[q] * 4u;
                 mwc0[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow0[q], 0);
                 mwc1[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow1[q], 0);
               }
@@ -964,17 +996,15 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
 
           // ---- byte boundary: MATCH (Predictor.cs:391-410), HCOMP, h[], rows of the next byte
           {
-            if (l_match) {                               // still with the h[i] of the byte just coded (update0 runs before z.run)
-              (slot_mem + hto)[m_limit & ht_mask] = (uint8_t)c;
-              m_limit = (m_limit + 1) & ht_mask;
-              uint32_t *cm = reinterpret_cast<uint32_t *>(slot_mem + cmo);
-              cm[hv & cm_mask] = m_limit;                // (its old value: cm_pre)
+            if (SP::match_lane >= 0) {                   // still with the h[i] of the byte just coded (update0 runs before z.run)
+              __builtin_amdgcn_raw_buffer_store_b8((uint8_t)c, rsrc, l_match ? hto + (m_limit & ht_mask) : kOob, 0, 0);
+              m_limit = l_match ? (m_limit + 1) & ht_mask : m_limit;
+              __builtin_amdgcn_raw_buffer_store_b32(m_limit, rsrc, l_match ? cmo + (hv & cm_mask) * 4u : kOob, 0, 0);   // (its old value: cm_pre)
             }
             if (HELP) {
               // ---- two-wave form: the helper wave ran HCOMP for this byte's value among 16 and staged what follows
               c2_put0(&S.mb_byte, bseq << 8 | (uint32_t)c);
-              uint32_t sp = 0;
-              while (helper_ok && c2_ld(&S.mb_ready) != bseq) { if (++sp > kC2Spin) helper_ok = false; }
+              if (helper_ok) helper_ok = c2_wait(&S.mb_ready, bseq);
               if (!helper_ok) { status = -24; break; }       // ZPAQHIP_E_HIP: the helper wavefront stopped answering (cannot happen by design)
               asm volatile("" ::: "memory");
               const uint32_t lo = (uint32_t)c & 15u;
@@ -994,15 +1024,15 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               }
 #pragma unroll
               for (uint32_t q = 0; q < SP::nmix; ++q) {
-                mx_h[q] = rdlane(hv, SP::mix_lane[q]);
-                mrow[q] = mix_row(q, mx_h[q], 1u);
+                mix_set(q, rdlane(hv, SP::mix_lane[q]));
+                mrow[q] = mix_row(q, 1u);
                 const uint32_t jj = lane - SP::mix_j0[q];
                 mw[q] = jj < SP::mix_m[q] ? (int)S.mixst[q][lo][jj & 15u] : 0;
               }
               ++bseq;
               if (SP::match_lane >= 0) {
                 match_boundary((uint32_t)c);
-                if (l_match) cm_pre = reinterpret_cast<uint32_t *>(slot_mem + cmo)[hv & cm_mask];
+                cm_pre = __builtin_amdgcn_raw_buffer_load_b32(rsrc, l_match ? cmo + (hv & cm_mask) * 4u : kOob, 0, 0);
               }
               C2_STAMP(6);
               rows_finish2(pr, old1, old1_off, old1_valid, old, old_off, old_valid);
@@ -1026,8 +1056,8 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             rows_issue(1u, pr);
 #pragma unroll
             for (uint32_t q = 0; q < SP::nmix; ++q) {
-              mx_h[q] = rdlane(hv, SP::mix_lane[q]);
-              mrow[q] = mix_row(q, mx_h[q], 1u);
+              mix_set(q, rdlane(hv, SP::mix_lane[q]));
+              mrow[q] = mix_row(q, 1u);
               mw[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow[q], 0);
             }
             if (SP::has_tail) {
@@ -1037,7 +1067,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             }
             if (SP::match_lane >= 0) {
               match_boundary((uint32_t)c);
-              if (l_match) cm_pre = reinterpret_cast<uint32_t *>(slot_mem + cmo)[hv & cm_mask];
+              cm_pre = __builtin_amdgcn_raw_buffer_load_b32(rsrc, l_match ? cmo + (hv & cm_mask) * 4u : kOob, 0, 0);
             }
             C2_STAMP(6);
             rows_finish(pr, old, old_off, old_valid);
