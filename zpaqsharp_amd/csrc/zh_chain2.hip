@@ -43,7 +43,7 @@ namespace {
 struct C2Min {                               // 0 icm 16 ; 1 isse 19 0
   static constexpr uint32_t id = 1, n = 2, depth = 1, final_lane = 1, nmix = 0, hh = 1, hm = 2;
   static constexpr uint64_t icm = 0x1, isse = 0x2;
-  static constexpr bool helper = true;
+  static constexpr int helper = 1;            // helper wave: HCOMP, hash rows and mixer rows of the next byte
   static constexpr int match_lane = -1;
   static constexpr uint32_t mix_lane[2] = {0, 0}, mix_j0[2] = {0, 0}, mix_m[2] = {0, 0};
   static constexpr bool has_tail = false;
@@ -51,7 +51,7 @@ struct C2Min {                               // 0 icm 16 ; 1 isse 19 0
 struct C2Mid {                               // 0 icm ; 1-5 isse ; 6 match ; 7 mix 16 0 7 24 255
   static constexpr uint32_t id = 2, n = 8, depth = 5, final_lane = 7, nmix = 1, hh = 3, hm = 3;
   static constexpr uint64_t icm = 0x01, isse = 0x3e;
-  static constexpr bool helper = true;
+  static constexpr int helper = 1;            // helper wave: HCOMP, hash rows and mixer rows of the next byte
   static constexpr int match_lane = 6;
   static constexpr uint32_t mix_lane[2] = {7, 0}, mix_j0[2] = {0, 0}, mix_m[2] = {7, 0};
   static constexpr bool has_tail = false;
@@ -63,7 +63,7 @@ struct C2Max {                               // Compressor.cs:60-72: 0 const; 1 
                                              // 15 mix 16 0 15 24 255; 16 mix 8 0 16 10 255; 17 mix2 0 15 16 24 0; 18 sse 8 17 32 255;
                                              // 19 mix2 8 17 18 16 255; 20 sse 16 19 32 255; 21 mix2 0 19 20 16 0
   static constexpr uint32_t id = 3, n = 22, depth = 6, final_lane = 21, nmix = 2, hh = 5, hm = 9;
-  static constexpr bool helper = false;      // (its LDS is full: 157 KB; the helper wave's staging does not fit yet)
+  static constexpr int helper = 2;            // helper wave: HCOMP only (LDS has no room for staged rows)
   static constexpr uint64_t icm = (1u << 1) | (1u << 9) | (1u << 11) | (1u << 12) | (1u << 13) | (1u << 14), isse = 0xfcu | (1u << 10);
   static constexpr int match_lane = 8;
   static constexpr uint32_t mix_lane[2] = {15, 16}, mix_j0[2] = {0, 0}, mix_m[2] = {15, 16};
@@ -76,8 +76,8 @@ struct C2Max {                               // Compressor.cs:60-72: 0 const; 1 
 constexpr int kHWords = 256, kMBytes = 4096, kCodeBytes = 2048, kPHWords = 256, kPMBytes = 1024;
 constexpr int kEntUnits = 15;                 // ICM / ISSE entry tables of 256 x 8 bytes
 
-constexpr int kSpecUnits = 8, kSpecH = 8;      // helper wave staging: ICM/ISSE components and H words per candidate (min / mid)
-template <bool TAIL, bool HELP>
+constexpr int kSpecUnits = 8, kSpecH = 8, kSpecHMax = 32;      // helper wave staging: ICM/ISSE components and H words per candidate (min / mid)
+template <bool TAIL, int HELP>
 struct alignas(16) C2LdsT {
   int16_t stretch[32768];                     // at LDS offset 0 of this struct: see lds_stretch()
   uint16_t squash[4096];
@@ -92,9 +92,9 @@ struct alignas(16) C2LdsT {
   uint32_t sse18[TAIL ? 256 * 32 : 1];        // max: the table of `sse 8 17` (h = 0: row = c8), Predictor.cs:163-164
   uint16_t a19[TAIL ? 256 : 2];               // max: the weights of `mix2 8 17 18`
   // helper wave (HELP): what it prepares for the NEXT byte, for each of the 16 values the current byte can still take
-  uint32_t hspec[HELP ? kSpecH : 1][16];      // H[d] after HCOMP(candidate)
-  v4u_ rowst[HELP ? kSpecUnits : 1][3][16];   // the three candidate hash rows of every ICM / ISSE for c8 = 1
-  uint32_t mixst[HELP ? 2 : 1][16][16];       // the mixer rows for c8 = 1
+  uint32_t hspec[HELP == 2 ? kSpecHMax : HELP == 1 ? kSpecH : 1][16];      // H[d] after HCOMP(candidate)
+  v4u_ rowst[HELP == 1 ? kSpecUnits : 1][3][16];   // the three candidate hash rows of every ICM / ISSE for c8 = 1
+  uint32_t mixst[HELP == 1 ? 2 : 1][16][16];       // the mixer rows for c8 = 1
   uint32_t mb_nib, mb_byte, mb_ready;         // A -> B: seq << 8 | first nibble / byte;  B -> A: seq whose staging is complete
   uint32_t mb_cmd, mb_ack, mb_model;          // A -> B: block start / end / exit
   uint32_t hreg[kHWords];
@@ -106,7 +106,7 @@ struct alignas(16) C2LdsT {
   Vm hz, pz;
   Sink sink;
 };
-static_assert(sizeof(C2LdsT<true, false>) <= 163840 && sizeof(C2LdsT<false, true>) <= 163840, "LDS budget");
+static_assert(sizeof(C2LdsT<true, 2>) <= 163840 && sizeof(C2LdsT<false, 1>) <= 163840, "LDS budget");
 
 typedef __attribute__((address_space(3))) uint8_t *lds_u8_p;
 typedef __attribute__((address_space(3))) uint16_t *lds_u16_p;
@@ -254,8 +254,9 @@ __device__ constexpr uint32_t c2_units() {
 // candidate's machine state.  B never decides anything: a late B only makes A wait.
 template <class SP, class LDS>
 __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
-  constexpr uint32_t NU = c2_units<SP>(), NH = 1u << SP::hh;
-  static_assert(NU <= (uint32_t)kSpecUnits && NH <= (uint32_t)kSpecH, "staging size");
+  constexpr bool ROWS = SP::helper == 1;                 // min / mid: rows and mixer weights too; max: HCOMP only
+  constexpr uint32_t NU = ROWS ? c2_units<SP>() : 0u, NH = 1u << SP::hh;
+  static_assert(NU <= (uint32_t)kSpecUnits && NH <= (uint32_t)(ROWS ? kSpecH : kSpecHMax), "staging size");
   uint8_t *slot_mem = L.arena + (uint64_t)blockIdx.x * L.arena_stride;
   const uint32_t cand = lane & 15u, grp = lane >> 4;
   uint32_t seen_cmd = 0;
@@ -309,11 +310,13 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
       const SpecM sm{(lds_u8_p)lds_off(S.mreg), &wi, &wv, &wn};
       const SpecH<NH> sh{(lds_u32_p)lds_off(S.hreg), hs, &wmask};
       if constexpr (SP::id == 1) (void)zh_native_hcomp_min(sa, sb, sc, sd, sf, x, sm, (1u << SP::hm) - 1u, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
+      else if constexpr (SP::id == 3) (void)zh_native_hcomp_max(sa, sb, sc, sd, sf, x, sm, (1u << SP::hm) - 1u, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
       else (void)zh_native_hcomp_mid(sa, sb, sc, sd, sf, x, sm, (1u << SP::hm) - 1u, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
       if (grp == 0) {
 #pragma unroll
         for (uint32_t d = 0; d < NH; ++d) S.hspec[d][cand] = (uint32_t)sh[d];
       }
+      if constexpr (ROWS) {
       // ---- rows of the first nibble of the next byte (c8 = 1): Predictor.find's three candidates per component
       v4u rr[2][3];
 #pragma unroll
@@ -354,6 +357,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
       for (uint32_t q = 0; q < SP::nmix; ++q)
 #pragma unroll
         for (uint32_t t = 0; t < 4; ++t) S.mixst[q][cand][grp + 4u * t] = mwv[q][t];
+      }
       asm volatile("" ::: "memory");
       c2_put0(&S.mb_ready, seq);
       // ---- the byte: commit its candidate
@@ -388,7 +392,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
 
 __device__ __forceinline__ void c2_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }   // one wave: no barrier
 
-template <class SP, bool PROF, bool HELP, class LDS>
+template <class SP, bool PROF, int HELP, class LDS>
 __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
   uint64_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tprev = 0;
@@ -1002,13 +1006,16 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               __builtin_amdgcn_raw_buffer_store_b32(m_limit, rsrc, l_match ? cmo + (hv & cm_mask) * 4u : kOob, 0, 0);   // (its old value: cm_pre)
             }
             if (HELP) {
-              // ---- two-wave form: the helper wave ran HCOMP for this byte's value among 16 and staged what follows
+              // ---- two-wave form: the helper wave ran HCOMP for this byte's value among 16 (and staged what follows)
               c2_put0(&S.mb_byte, bseq << 8 | (uint32_t)c);
               if (helper_ok) helper_ok = c2_wait(&S.mb_ready, bseq);
               if (!helper_ok) { status = -24; break; }       // ZPAQHIP_E_HIP: the helper wavefront stopped answering (cannot happen by design)
               asm volatile("" ::: "memory");
+              hv = S.hspec[lane & ((1u << SP::hh) - 1u)][(uint32_t)c & 15u];
+              ++bseq;
+            }
+            if (HELP == 1) {
               const uint32_t lo = (uint32_t)c & 15u;
-              hv = S.hspec[lane & ((1u << SP::hh) - 1u)][lo];
               C2_STAMP(5);
               v4u old; uint32_t old_off; bool old_valid;
               row_evict(old, old_off, old_valid);
@@ -1029,7 +1036,6 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
                 const uint32_t jj = lane - SP::mix_j0[q];
                 mw[q] = jj < SP::mix_m[q] ? (int)S.mixst[q][lo][jj & 15u] : 0;
               }
-              ++bseq;
               if (SP::match_lane >= 0) {
                 match_boundary((uint32_t)c);
                 cm_pre = __builtin_amdgcn_raw_buffer_load_b32(rsrc, l_match ? cmo + (hv & cm_mask) * 4u : kOob, 0, 0);
@@ -1039,6 +1045,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               asm volatile("" ::: "memory");
               C2_STAMP(7);
             } else {
+            if (!HELP) {
             int rc;
             switch (hnative) {
               case ZH_NATIVE_HCOMP_MIN: rc = zh_native_hcomp_min(ha, hb, hc, hd, hf, (uint32_t)c, reg_m, hz.mmask, lds_h, hmask, S.r, (Sink *)nullptr, L.budget); break;
@@ -1049,6 +1056,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             rc = (int)uni((uint32_t)rc);
             if (rc) { status = rc; break; }
             hv = lds_h[lane & hmask];
+            }
             C2_STAMP(5);
             v4u old; uint32_t old_off; bool old_valid;
             row_evict(old, old_off, old_valid);
@@ -1138,7 +1146,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
 }  // namespace
 
 #define ZH_CHAIN2_KERNEL(name, spec, prof)                                             \
-  extern "C" __global__ __launch_bounds__(spec::helper ? 128 : 64) void name(ZhLaunch L) { \
+  extern "C" __global__ __launch_bounds__(spec::helper ? 128 : 64) void name(ZhLaunch L) {  \
     typedef C2LdsT<spec::has_tail, spec::helper> Lds;                                  \
     __shared__ Lds S;                                                                  \
     decode_chain2_body<spec, prof, spec::helper, Lds>(L, S);                           \
@@ -1154,7 +1162,7 @@ extern "C" hipError_t zh_launch_chain2(const ZhLaunch *L, uint32_t grid, hipStre
   void (*k)(ZhLaunch) = spec == 1 ? zh_decode_c2_min : spec == 2 ? zh_decode_c2_mid : spec == 3 ? zh_decode_c2_max : nullptr;
   if (prof && spec >= 2) k = spec == 2 ? zh_decode_c2_mid_prof : zh_decode_c2_max_prof;
   if (!k) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(spec == 3 ? 64 : 128), 0, stream, *L);     // min / mid: decoder wave + helper wave
+  hipLaunchKernelGGL(k, dim3(grid), dim3(128), 0, stream, *L);     // decoder wave + helper wave
   return hipGetLastError();
 }
 extern "C" int zh_chain2_has(uint32_t spec) { return spec >= 1 && spec <= 3; }

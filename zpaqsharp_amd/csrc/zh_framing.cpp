@@ -428,7 +428,7 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
     uint32_t spec = zh_spec_lookup(hdr, len);                            // {0 none, 1 min, 2 mid, 3 max}
     const uint32_t native = zh_native_lookup(hdr + cp, m.hcomp_len);     // native HCOMP id or 0
     // zh_chain2.hip's max code relies on what the built-in HCOMP leaves in h[17..21] (zeros, and an even h[20])
-    if (spec == 3 && native != ZH_NATIVE_HCOMP_MAX) spec = 0;
+    if (spec == 3 && (native != ZH_NATIVE_HCOMP_MAX || m.hh != 5 || m.hm != 9)) spec = 0;
     // ... its min / mid code hands HCOMP to a helper wavefront that runs the translated program of that model for 16
     // candidate bytes at once, with H and M of exactly the built-in sizes
     if (spec == 1 && (native != ZH_NATIVE_HCOMP_MIN || m.hh != 1 || m.hm != 2)) spec = 0;
