@@ -378,9 +378,12 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
 
 // Diagnostic build (PROF): cycles per stage, summed per block into L.debug[0..7].  Stamps wait for LDS/scalar results
 // only (global memory stays in flight, as in the real kernel).
+#ifndef C2_PROF_MASK
+#define C2_PROF_MASK 0xfff                      /* stages the *_prof kernels stamp (fewer stamps: less distortion) */
+#endif
 #define C2_STAMP(i)                                                                                  \
   do {                                                                                               \
-    if (PROF) {                                                                                      \
+    if (PROF && ((C2_PROF_MASK >> (i)) & 1)) {                                                                                   \
       uint64_t now_;                                                                                 \
       __builtin_amdgcn_sched_barrier(0);                                                             \
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
@@ -599,6 +602,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     // ---- state carried from bit to bit
     uint32_t hv = 0;                                    // h[lane] (Predictor.cs:469)
     uint32_t rowoff = 0;                                // arena offset of the hash row held in S.slot[lane]
+    uint32_t row_x = 0;                                 // first dword of that row as it was when the nibble began
     bool rowvalid = false;
     uint32_t ea = tab;                                  // LDS address of the entry the current bit uses
     uint32_t st = 0;                                    // its bit-history state
@@ -694,6 +698,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
       const v4u row = m0 ? r0 : m1 ? r1 : m2 ? r2 : fresh;
       *(lds_u4_p)lds_off(&S.slot[lane]) = row;           // lanes without a hash table never read their slot
       rowoff = sel; rowvalid = true;
+      row_x = l_ii ? row.x : 0u;                          // bytes 1-3: the histories of nodes 1, 2, 3 (no LDS round trip for them)
     };
     auto rows_finish = [&](const Probe &pr, const v4u &old, uint32_t old_off, bool old_valid) __attribute__((always_inline)) {
       rows_finish2(pr, old, 0u, false, old, old_off, old_valid);
@@ -706,7 +711,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     };
     // first bit of a nibble: node 1 of the row now in S.slot, read directly
     auto l0_direct = [&]() __attribute__((always_inline)) {
-      st = *(lds_u8_p)(rrow + 1);
+      st = (row_x >> 8) & 255u;
       ea = tab + st * 8u;
       const v2u e = *(lds_u2_p)ea;
       eA = e.x; eB = e.y;
@@ -804,7 +809,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             if (SP::match_lane >= 0 && bit == 4) match_prefetch();
             uint32_t ea0 = 0, ea1 = 0;
             v2u e0 = {0, 0}, e1 = e0;
-            if (pre_ii) pairS = *(lds_u16_p)(rrow + 2u * hm);
+            if (pre_ii) pairS = (bit & 3) == 0 ? row_x >> 16 : (uint32_t)*(lds_u16_p)(rrow + 2u * hm);
             int mwc0[2] = {0, 0}, mwc1[2] = {0, 0};
             uint32_t mrow0[2] = {0, 0}, mrow1[2] = {0, 0};
             if (pre_mx) {
@@ -1008,6 +1013,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             if (HELP) {
               // ---- two-wave form: the helper wave ran HCOMP for this byte's value among 16 (and staged what follows)
               c2_put0(&S.mb_byte, bseq << 8 | (uint32_t)c);
+              C2_STAMP(11);
               if (helper_ok) helper_ok = c2_wait(&S.mb_ready, bseq);
               if (!helper_ok) { status = -24; break; }       // ZPAQHIP_E_HIP: the helper wavefront stopped answering (cannot happen by design)
               asm volatile("" ::: "memory");
