@@ -118,8 +118,9 @@ int zpaqhip_ctx_create(int device, zpaqhip_ctx **out, zpaqhip_err *err) {
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
-      (e = c->tables.reserve(sizeof(ZhTables))) != hipSuccess ||
-      (e = hipMemcpy(c->tables.p, &host_tables(), sizeof(ZhTables), hipMemcpyHostToDevice)) != hipSuccess) {
+      (e = c->tables.reserve(sizeof(ZhTables) + sizeof(ZhTablesX))) != hipSuccess ||
+      (e = hipMemcpy(c->tables.p, &host_tables(), sizeof(ZhTables), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy((uint8_t *)c->tables.p + sizeof(ZhTables), &host_tables_x(), sizeof(ZhTablesX), hipMemcpyHostToDevice)) != hipSuccess) {
     char m[112];
     snprintf(m, sizeof m, "HIP: %s (context setup)", hipGetErrorString(e));
     set_err(err, ZPAQHIP_E_HIP, -1, -1, m);

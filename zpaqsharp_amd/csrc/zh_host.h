@@ -14,6 +14,7 @@ namespace zh {
 // zh_tables.cpp — model-independent tables, generated and pinned against the
 // reference's self-check constants (Predictor.cs:71-77) and the state-table CRC.
 const ZhTables &host_tables();           // aborts the call chain via ok=false if pins fail
+const ZhTablesX &host_tables_x();        // derived (zh_model.h); uploaded right behind ZhTables
 bool host_tables_ok();
 
 // zh_framing.cpp

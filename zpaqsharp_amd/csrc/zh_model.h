@@ -99,6 +99,13 @@ struct ZhTables {          // Predictor.cs:48-79 + StateTable.cs
   uint8_t ns[1024];
 };
 
+// Follows ZhTables in the same device buffer.  ps[p + 2048] = (squash(p) * 2 + 1) << 16: the arithmetic decoder's split
+// factor for prediction p (Decoder.cs:136-140), ready for s_mul_hi_u32; read through the scalar cache by kernels whose
+// critical path is one wave (a dependent s_load costs ~80 cycles there, ds_read + v_readlane ~120: tools/ubench/lat_bench).
+struct ZhTablesX {
+  uint32_t ps[4096];
+};
+
 struct ZhLaunch {          // kernel arguments (one struct, passed by value)
   const uint8_t *in;
   const ZhModel *models;

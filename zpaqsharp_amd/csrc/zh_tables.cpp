@@ -72,6 +72,7 @@ uint32_t crc32(const uint8_t *p, size_t n) {
 
 struct Built {
   ZhTables t;
+  ZhTablesX x;
   bool ok;
   Built() {
     t.dt2k[0] = 0;
@@ -82,6 +83,7 @@ struct Built {
     for (int i = 16384; i < 32768; ++i)
       t.stretch[i] = (int16_t)((int)(log((i + 0.5) / (32767.5 - i)) * 64 + 0.5 + 100000) - 100000);
     for (int i = 0; i < 16384; ++i) t.stretch[i] = (int16_t)-t.stretch[32767 - i];
+    for (int i = 0; i < 4096; ++i) x.ps[i] = ((uint32_t)t.squash[i] * 2 + 1) << 16;
     StateGen::build(t.ns);
     uint32_t st = 0, sq = 0;
     for (int i = 32767; i >= 0; --i) st = st * 3 + (uint32_t)(int)t.stretch[i];
@@ -98,6 +100,7 @@ const Built &built() {
 }  // namespace
 
 const ZhTables &host_tables() { return built().t; }
+const ZhTablesX &host_tables_x() { return built().x; }
 bool host_tables_ok() { return built().ok; }
 
 }  // namespace zh
