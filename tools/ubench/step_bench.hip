@@ -95,6 +95,30 @@
   "v_readlane_b32 s94, %[pv], %[j]\n\t"        \
   STEP_C("s94", "s95") STEP_C("s95", "s94") STEP_C("s94", "s95") STEP_C("s95", "s94")
 
+
+// ... versus selecting the lane through exec: s_lshl_b64 exec, 1, j ; v_readfirstlane (no SGPR lane select)
+#define NIB_D                                  \
+  "s_mov_b32 %[j], 1\n\t"                      \
+  "s_lshl_b64 exec, 1, %[j]\n\tv_readfirstlane_b32 s94, %[pv]\n\t" CORE("s94") SPLIT TAIL \
+  "s_lshl_b64 exec, 1, %[j]\n\tv_readfirstlane_b32 s94, %[pv]\n\t" CORE("s94") SPLIT TAIL \
+  "s_lshl_b64 exec, 1, %[j]\n\tv_readfirstlane_b32 s94, %[pv]\n\t" CORE("s94") SPLIT TAIL \
+  "s_lshl_b64 exec, 1, %[j]\n\tv_readfirstlane_b32 s94, %[pv]\n\t" CORE("s94") SPLIT TAIL \
+  "s_mov_b64 exec, -1\n\t"
+// ... versus all 15 nodes of the nibble read into SGPRs with constant lane selects, narrowed by s_cselect as bits arrive
+// s[60:61]=n2,n3  s[62:65]=n4..n7  s[66:73]=n8..n15 ; after bit1: s[62:63] pair, s[66:69] quad; after bit2: s62, s[66:67]; after bit3: s66
+#define RL(S, L) "v_readlane_b32 " S ", %[pv], " L "\n\t"
+#define NIB_E                                  \
+  "s_mov_b32 %[j], 1\n\t"                      \
+  RL("s94","1") RL("s60","2") RL("s61","3") RL("s62","4") RL("s63","5") RL("s64","6") RL("s65","7") \
+  RL("s66","8") RL("s67","9") RL("s68","10") RL("s69","11") RL("s70","12") RL("s71","13") RL("s72","14") RL("s73","15") \
+  CORE("s94") SPLIT                            \
+  "s_cselect_b32 s94, s61, s60\n\ts_cselect_b64 s[62:63], s[64:65], s[62:63]\n\ts_cselect_b64 s[66:67], s[70:71], s[66:67]\n\ts_cselect_b64 s[68:69], s[72:73], s[68:69]\n\t" TAIL \
+  CORE("s94") SPLIT                            \
+  "s_cselect_b32 s94, s63, s62\n\ts_cselect_b64 s[66:67], s[68:69], s[66:67]\n\t" TAIL \
+  CORE("s94") SPLIT                            \
+  "s_cselect_b32 s94, s67, s66\n\t" TAIL       \
+  CORE("s94") SPLIT TAIL
+
 __global__ void k(uint64_t *out, uint32_t seed, int spin) {
   __shared__ uint32_t flag[4];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -146,6 +170,20 @@ __global__ void k(uint64_t *out, uint32_t seed, int spin) {
                  : "scc", "s84", "s85", "s86", "s87", "s88", "s94", "s95", "s96");
     STAMP(t1); out[n++] = t1 - t0;
   }
+  low = 1; high = 0xFFFFFFF0u;
+  for (int rep = 0; rep < 2; ++rep) {
+    STAMP(t0);
+    asm volatile(REP4(NIB_D) "9:\n\ts_mov_b64 exec, -1\n\t" : [low] "+s"(low), [high] "+s"(high), [curr] "+s"(curr), [j] "+s"(j) : [pv] "v"(pv)
+                 : "scc", "s84", "s85", "s86", "s87", "s88", "s94", "s95", "s96");
+    STAMP(t1); out[n++] = t1 - t0;
+  }
+  low = 1; high = 0xFFFFFFF0u;
+  for (int rep = 0; rep < 2; ++rep) {
+    STAMP(t0);
+    asm volatile(REP4(NIB_E) "9:\n\t" : [low] "+s"(low), [high] "+s"(high), [curr] "+s"(curr), [j] "+s"(j) : [pv] "v"(pv)
+                 : "scc", "s84", "s85", "s86", "s87", "s88", "s94", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73");
+    STAMP(t1); out[n++] = t1 - t0;
+  }
   // pieces
   STAMP(t0);
   asm volatile(REP16("v_readlane_b32 s94, %[pv], %[j]\n\ts_add_u32 %[j], s94, 1\n\ts_and_b32 %[j], %[j], 63\n\t") : [j] "+s"(j) : [pv] "v"(pv) : "scc", "s94");
@@ -165,7 +203,7 @@ __global__ void k(uint64_t *out, uint32_t seed, int spin) {
 int main() {
   uint64_t *d;
   hipMalloc(&d, 256);
-  const char *names[] = {"STEP x16 (cold)", "STEP x16", "STEP2 x16 (cold)", "STEP2 x16", "4 nibbles, readlane per step (cold)", "4 nibbles, readlane per step", "4 nibbles, children pairs (cold)", "4 nibbles, children pairs", "4 nibbles, early fetch (cold)", "4 nibbles, early fetch", "readlane->2 salu x16 (48)", "mul_hi->add x16 (32)",
+  const char *names[] = {"STEP x16 (cold)", "STEP x16", "STEP2 x16 (cold)", "STEP2 x16", "4 nibbles, readlane per step (cold)", "4 nibbles, readlane per step", "4 nibbles, children pairs (cold)", "4 nibbles, children pairs", "4 nibbles, early fetch (cold)", "4 nibbles, early fetch", "4 nibbles, exec + readfirstlane (cold)", "4 nibbles, exec + readfirstlane", "4 nibbles, 15 nodes in SGPRs (cold)", "4 nibbles, 15 nodes in SGPRs", "readlane->2 salu x16 (48)", "mul_hi->add x16 (32)",
                          "cmp->cselect x16 (32)", "empty stamp pair"};
   for (int spin = 0; spin < 2; ++spin) {
     for (int rep = 0; rep < 2; ++rep) {
@@ -175,7 +213,7 @@ int main() {
     uint64_t o[32];
     hipMemcpy(o, d, 256, hipMemcpyDeviceToHost);
     printf("second wave: %s\n", spin == 0 ? "exits at once" : spin == 1 ? "polls LDS flat out" : "polls LDS with s_sleep 2");
-    for (int i = 0; i < 14; ++i) printf("  %-32s %6llu cycles\n", names[i], (unsigned long long)o[i]);
+    for (int i = 0; i < 18; ++i) printf("  %-32s %6llu cycles\n", names[i], (unsigned long long)o[i]);
   }
   return 0;
 }

@@ -684,15 +684,21 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     };
     // (olda, oldb: rows this wave evicted after the probe's loads may have been issued — by itself or by the helper wave)
     auto rows_finish2 = [&](const Probe &pr, const v4u &olda, uint32_t olda_off, bool olda_valid, const v4u &old, uint32_t old_off,
-                            bool old_valid) __attribute__((always_inline)) {
+                            bool old_valid, bool guard) __attribute__((always_inline)) {
       const uint32_t h0 = pr.h0, h1 = h0 ^ 16u, h2 = h0 ^ 32u;
       v4u r0 = pr.r0, r1 = pr.r1, r2 = pr.r2;
-      if (olda_valid && olda_off == h0) r0 = olda;
-      if (olda_valid && olda_off == h1) r1 = olda;
-      if (olda_valid && olda_off == h2) r2 = olda;
-      if (old_valid && old_off == h0) r0 = old;
-      if (old_valid && old_off == h1) r1 = old;
-      if (old_valid && old_off == h2) r2 = old;
+      // an evicted row lands in the new bucket only when two contexts share it.  guard: one test for the wave and the
+      // patch behind a branch (the byte boundary); without it the selects run always (the nibble switch, where the four
+      // copies of this code would each bring a taken branch)
+      const bool near = (olda_valid && ((olda_off ^ h0) & ~48u) == 0) || (old_valid && ((old_off ^ h0) & ~48u) == 0);
+      if (!guard || UNLIKELY(__ballot(near) != 0)) {
+        if (olda_valid && olda_off == h0) r0 = olda;
+        if (olda_valid && olda_off == h1) r1 = olda;
+        if (olda_valid && olda_off == h2) r2 = olda;
+        if (old_valid && old_off == h0) r0 = old;
+        if (old_valid && old_off == h1) r1 = old;
+        if (old_valid && old_off == h2) r2 = old;
+      }
       const uint32_t chk = pr.chk;
       const bool m0 = (r0.x & 255) == chk, m1 = (r1.x & 255) == chk, m2 = (r2.x & 255) == chk;
       const uint32_t p0 = (r0.x >> 8) & 255, p1 = (r1.x >> 8) & 255, p2 = (r2.x >> 8) & 255;
@@ -705,7 +711,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
       row_x = l_ii ? row.x : 0u;                          // bytes 1-3: the histories of nodes 1, 2, 3 (no LDS round trip for them)
     };
     auto rows_finish = [&](const Probe &pr, const v4u &old, uint32_t old_off, bool old_valid) __attribute__((always_inline)) {
-      rows_finish2(pr, old, 0u, false, old, old_off, old_valid);
+      rows_finish2(pr, old, 0u, false, old, old_off, old_valid, false);
     };
     // write the row of the finished nibble back (fire and forget) and hand its content to the caller
     auto row_evict = [&](v4u &old, uint32_t &old_off, bool &old_valid) __attribute__((always_inline)) {
@@ -1057,7 +1063,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
                 cm_pre = __builtin_amdgcn_raw_buffer_load_b32(rsrc, l_match ? cmo + (hv & cm_mask) * 4u : kOob, 0, 0);
               }
               C2_STAMP(6);
-              rows_finish2(pr, old1, old1_off, old1_valid, old, old_off, old_valid);
+              rows_finish2(pr, old1, old1_off, old1_valid, old, old_off, old_valid, true);
               asm volatile("" ::: "memory");
               C2_STAMP(7);
             } else {
