@@ -257,9 +257,10 @@ __device__ constexpr uint32_t c2_units() {
 // candidate's machine state.  B never decides anything: a late B only makes A wait.
 template <class SP, class LDS>
 __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
-  constexpr bool ROWS = SP::helper == 1;                 // min / mid: rows and mixer weights too; max: HCOMP only
-  constexpr uint32_t NU = ROWS ? c2_units<SP>() : 0u, NH = 1u << SP::hh;
-  static_assert(NU <= (uint32_t)kSpecUnits && NH <= (uint32_t)(ROWS ? kSpecH : kSpecHMax), "staging size");
+  constexpr bool ROWS = SP::helper == 1;                 // min / mid: rows and mixer weights staged in LDS too
+  constexpr bool TOUCH = SP::helper == 2;                // max (no LDS left): HCOMP, and the lines of those rows pulled towards L2
+  constexpr uint32_t NU = c2_units<SP>(), NH = 1u << SP::hh, RN = ROWS ? 2u : (NU + 3u) / 4u;
+  static_assert((!ROWS || NU <= (uint32_t)kSpecUnits) && NU <= 16u && NH <= (uint32_t)(ROWS ? kSpecH : kSpecHMax), "staging size");
   uint8_t *slot_mem = L.arena + (uint64_t)blockIdx.x * L.arena_stride;
   const uint32_t cand = lane & 15u, grp = lane >> 4;
   uint32_t seen_cmd = 0;
@@ -274,17 +275,17 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
     const uint32_t arena_bytes = uni((uint32_t)M->arena_bytes);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slot_mem, 0, (int)arena_bytes, 0x00020000);
     // this lane's units: u = grp, grp + 4 (rows of unit u for candidate `cand`)
-    uint32_t u_hto[2], u_mask[2], u_sb2[2], u_comp[2];
-    bool u_on[2];
+    uint32_t u_hto[RN], u_mask[RN], u_comp[RN];
+    bool u_on[RN];
 #pragma unroll
-    for (uint32_t r = 0; r < 2; ++r) {
+    for (uint32_t r = 0; r < RN; ++r) {
       const uint32_t u = grp + 4u * r;
       u_on[r] = u < NU;
       uint32_t ci = 0;
 #pragma unroll
       for (uint32_t k = 0; k < NU; ++k) if (k == u) ci = c2_unit_comp<SP>(k);
       const ZhComp *cp = &M->comp[ci];
-      u_comp[r] = ci; u_hto[r] = (uint32_t)cp->ht_off; u_mask[r] = cp->ht_mask; u_sb2[r] = (uint32_t)cp->arg[0] + 2u;
+      u_comp[r] = ci; u_hto[r] = (uint32_t)cp->ht_off; u_mask[r] = cp->ht_mask;
     }
     uint32_t mx_base[2] = {0, 0}, mx_size1[2] = {0, 0};
 #pragma unroll
@@ -363,6 +364,28 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
       }
       asm volatile("" ::: "memory");
       c2_put0(&S.mb_ready, seq);
+      if constexpr (TOUCH) {
+        // The decoder wave will request the candidate's rows itself once the byte is known; one dword per (candidate,
+        // component) now brings the 64-byte line that holds all three probes of Predictor.find (h0, h0^16, h0^32) out of
+        // HBM, likewise the mixer row and the `sse 16` row pair.  Nothing is kept: the values are dropped.
+        uint32_t t[RN + 2];
+#pragma unroll
+        for (uint32_t r = 0; r < RN; ++r) {
+          const uint32_t hval = S.hspec[u_comp[r] & (NH - 1u)][cand];
+          const uint32_t h0 = ((hval + 16u) * 16u) & (u_mask[r] - 15u);
+          t[r] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, u_on[r] ? u_hto[r] + h0 : kOob, 0, 0);
+        }
+        {
+          const uint32_t hq = S.hspec[SP::mix_lane[0] & (NH - 1u)][cand];
+          const uint32_t row = mx_base[0] + ((hq + 1u) & mx_size1[0]) * (SP::mix_m[0] * 4u);
+          t[RN] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, grp < 2 ? row + grp * (SP::mix_m[0] * 4u - 4u) : kOob, 0, 0);
+          const ZhComp &sc20 = M->comp[20];
+          const uint32_t srow = ((S.hspec[20][cand] * 32u) & sc20.cm_mask) * 4u + (uint32_t)sc20.cm_off;
+          t[RN + 1] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, SP::has_tail ? srow + grp * 64u : kOob, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < RN + 2; ++r) asm volatile("" ::"v"(t[r]));
+      }
       // ---- the byte: commit its candidate
       sp = 0;
       while (((v = c2_ld(&S.mb_byte)) >> 8) != seq) {
