@@ -227,6 +227,44 @@ def test_full_size_blocks_of_the_chain_models(ctx, model, kind):
         assert np.array_equal(got[b * bs:(b + 1) * bs], synth.plain(kind, 1000 + b, bs)), b
 
 
+def _repetitive_plaintexts(n=48 << 10):
+    """Inputs whose consecutive contexts share hash rows, mixer rows and MATCH candidates: the cases in which a row the
+    decoder wave has just written back (or still holds) is also among the rows requested for the next nibble / byte —
+    by the decoder wave itself or, ahead of it, by the helper wave of zh_chain2.hip."""
+    rng = np.random.default_rng(77)
+    yield "zeros", np.zeros(n, np.uint8)
+    yield "ff", np.full(n, 255, np.uint8)
+    yield "period2", np.tile(np.array([0x41, 0x42], np.uint8), n // 2)
+    yield "period3", np.tile(np.array([1, 2, 3], np.uint8), n // 3 + 1)[:n]
+    yield "period256", np.tile(np.arange(256, dtype=np.uint8), n // 256)
+    yield "runs", np.repeat(rng.integers(0, 256, n // 64, dtype=np.uint8), 64)
+    yield "two_symbols", rng.integers(0, 2, n, dtype=np.uint8) * 0x0f + 0x10
+    yield "low_nibbles", rng.integers(0, 16, n, dtype=np.uint8)
+    yield "high_nibbles", (rng.integers(0, 16, n, dtype=np.uint8) << 4).astype(np.uint8)
+    rep = rng.integers(0, 256, 700, dtype=np.uint8)
+    yield "long_repeats", np.concatenate([rep, rng.integers(0, 256, 300, dtype=np.uint8)] * (n // 1000))
+
+
+@pytest.mark.parametrize("model", ["min", "mid", "max", "max+e8e9"])
+def test_chain_models_on_repetitive_plaintext(ctx, model):
+    """One stream of ten blocks per model; GPU output against the oracle's and the plaintext."""
+    names, plains, blocks = [], [], []
+    for name, d in _repetitive_plaintexts():
+        names.append(name)
+        plains.append(d.tobytes())
+        blocks.append(synth.compress_block(model, d))
+    s = b"".join(blocks)
+    want = b"".join(plains)
+    assert oracle.decompress(s, cap=len(want) + 16) == want
+    got = ctx.decompress(s, verify_sha1=True).tobytes()
+    assert ctx.stats().kernel_kind == 3
+    off = 0
+    for name, p_ in zip(names, plains):
+        assert got[off:off + len(p_)] == p_, (model, name)
+        off += len(p_)
+    assert len(got) == len(want)
+
+
 def test_two_ranks_on_one_gpu_run_the_sharded_hip_decode(tmp_path):
     """bench.py's N > 1 path — shared stream, broadcast table, LPT plan, zpaqhip_decode_blocks_device(ids = shard),
     all_gather of the results — rehearsed with two gloo ranks that share this box's one GPU."""

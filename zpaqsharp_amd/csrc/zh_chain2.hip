@@ -303,6 +303,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
       sp = 0;
       while (((v = c2_ld(&S.mb_nib)) >> 8) != seq) {
         if (c2_ld(&S.mb_cmd) != seen_cmd || ++sp > kC2Spin) { alive = false; break; }
+        __builtin_amdgcn_s_sleep(1);                     // (it has hundreds of cycles in hand: poll gently)
       }
       if (!alive) break;
       const uint32_t x = (v & 15u) << 4 | cand;
@@ -390,6 +391,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
       sp = 0;
       while (((v = c2_ld(&S.mb_byte)) >> 8) != seq) {
         if (c2_ld(&S.mb_cmd) != seen_cmd || ++sp > kC2Spin) { alive = false; break; }
+        __builtin_amdgcn_s_sleep(1);                     // (it has hundreds of cycles in hand: poll gently)
       }
       if (!alive) break;
       const uint32_t lo = v & 15u;
@@ -1013,18 +1015,21 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               v4u old; uint32_t old_off; bool old_valid;
               row_evict(old, old_off, old_valid);
               old1 = old; old1_off = old_off; old1_valid = old_valid;
-              if (HELP) {
-                // The helper wave now prepares the next byte for the 16 values this one can still take.  Everything this
-                // wave has stored so far has reached memory before the helper is told (vmcnt(0)); what it stores later
-                // that the helper's loads could miss — the two hash rows of this byte — is patched in from the copies
-                // kept here (old1, and the second nibble's row at the byte's end).
-                c2_put0(&S.mb_nib, bseq << 8 | (c8 & 15u));
-              }
               switch (c8 & 3u) {                         // wave-uniform: four copies of the selection code, no data selects
                 case 0: rows_finish(spec[0], old, old_off, old_valid); break;
                 case 1: rows_finish(spec[1], old, old_off, old_valid); break;
                 case 2: rows_finish(spec[2], old, old_off, old_valid); break;
                 default: rows_finish(spec[3], old, old_off, old_valid); break;
+              }
+              if (HELP) {
+                // The helper wave now prepares the next byte for the 16 values this one can still take.  What its loads
+                // see of this wave's stores: rows_finish above has consumed loads issued at bit 1, and vector memory
+                // operations complete in issue order, so every store up to bit 0 of this byte — the last byte boundary's
+                // row write-back, the mixer weights of the c8 = 1 row — has reached memory.  The two hash rows this wave
+                // writes later — the one just evicted and the second nibble's at the byte's end — are patched in from
+                // the copies kept here (old1, old) when the staged rows are taken.
+                asm volatile("" ::: "memory");
+                c2_put0(&S.mb_nib, bseq << 8 | (c8 & 15u));
               }
               hm = 1;
               l0_direct();

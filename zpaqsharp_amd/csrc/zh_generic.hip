@@ -8,8 +8,10 @@
 //     update0 (Predictor.cs:245-475)  ->  ZPAQL.run0 (ZPAQL.cs:1028-1265)
 //     ->  PostProcessor.write (PostProcessor.cs:37-86).
 // This kernel is the always-correct path for arbitrary headers (n up to 255,
-// any HCOMP/PCOMP); zh_lanes.hip holds the lane-parallel kernels used for the
-// models the host recognises.  Nothing here runs on the CPU.
+// any HCOMP/PCOMP); zh_cm.hip (single direct CM), zh_chain2.hip (the built-in
+// min / mid / max models) and zh_chain.hip (any chain of <= 64 components) hold
+// the lane-parallel kernels the host routes recognised models to.  Nothing here
+// runs on the CPU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
