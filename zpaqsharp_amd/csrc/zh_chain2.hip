@@ -301,9 +301,8 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
       // ---- the first nibble of byte #seq
       uint32_t v;
       sp = 0;
-      while (((v = c2_ld(&S.mb_nib)) >> 8) != seq) {
+      while (((v = c2_ld(&S.mb_nib)) >> 8) != seq) {        // (this one is on the clock: the decoder wave has 4 bits to go)
         if (c2_ld(&S.mb_cmd) != seen_cmd || ++sp > kC2Spin) { alive = false; break; }
-        __builtin_amdgcn_s_sleep(1);                     // (it has hundreds of cycles in hand: poll gently)
       }
       if (!alive) break;
       const uint32_t x = (v & 15u) << 4 | cand;
@@ -391,7 +390,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
       sp = 0;
       while (((v = c2_ld(&S.mb_byte)) >> 8) != seq) {
         if (c2_ld(&S.mb_cmd) != seen_cmd || ++sp > kC2Spin) { alive = false; break; }
-        __builtin_amdgcn_s_sleep(1);                     // (it has hundreds of cycles in hand: poll gently)
+        __builtin_amdgcn_s_sleep(1);                     // (nothing to do until the byte is known: poll gently)
       }
       if (!alive) break;
       const uint32_t lo = v & 15u;
