@@ -1014,22 +1014,22 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               v4u old; uint32_t old_off; bool old_valid;
               row_evict(old, old_off, old_valid);
               old1 = old; old1_off = old_off; old1_valid = old_valid;
+              // The helper wave is told the first nibble: it now prepares the next byte for the 16 values this one can
+              // still take.  What its loads must see of this wave's stores — the last byte boundary's row write-back, the
+              // c8 = 1 mixer row written at bit 0 — has reached memory by now: vector memory operations complete in issue
+              // order, and the value published here depends on data requested after those stores (mid, max: bit 3's
+              // decision went through mixer weights loaded at bit 2; min has no such load and publishes below, after
+              // rows_finish has consumed the rows requested at bit 1).  The two hash rows this wave writes later — the one
+              // just evicted and the second nibble's at the byte's end — are patched in from the copies kept here
+              // (old1, old) when the staged rows are taken.
+              if (HELP && SP::nmix > 0) c2_put0(&S.mb_nib, bseq << 8 | (c8 & 15u));
               switch (c8 & 3u) {                         // wave-uniform: four copies of the selection code, no data selects
                 case 0: rows_finish(spec[0], old, old_off, old_valid); break;
                 case 1: rows_finish(spec[1], old, old_off, old_valid); break;
                 case 2: rows_finish(spec[2], old, old_off, old_valid); break;
                 default: rows_finish(spec[3], old, old_off, old_valid); break;
               }
-              if (HELP) {
-                // The helper wave now prepares the next byte for the 16 values this one can still take.  What its loads
-                // see of this wave's stores: rows_finish above has consumed loads issued at bit 1, and vector memory
-                // operations complete in issue order, so every store up to bit 0 of this byte — the last byte boundary's
-                // row write-back, the mixer weights of the c8 = 1 row — has reached memory.  The two hash rows this wave
-                // writes later — the one just evicted and the second nibble's at the byte's end — are patched in from
-                // the copies kept here (old1, old) when the staged rows are taken.
-                asm volatile("" ::: "memory");
-                c2_put0(&S.mb_nib, bseq << 8 | (c8 & 15u));
-              }
+              if (HELP && SP::nmix == 0) c2_put0(&S.mb_nib, bseq << 8 | (c8 & 15u));     // min: see above
               hm = 1;
               l0_direct();
               C2_STAMP(4);
