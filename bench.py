@@ -129,10 +129,29 @@ def roofline(base_model, kms, plain_bytes, rho, nb, bs, model_tag):
             "measured_hbm_gbps": (tr["bytes"] / (kms * 1e-3) / 1e9) if tr else None,
             "algorithmic_bytes_per_launch": b_alg * plain_bytes, "alg_bytes_per_plain_byte": b_alg,
             "kernel_ms": kms,
-            "issue": {"blocks_in_flight": waves,
-                      "cycles_per_plain_byte_per_block": kms * 1e-3 * CLOCK_GHZ * 1e9 / (plain_bytes / waves),
-                      "note": "the operative bound is the dependent instruction chain of the wave that owns a block; "
-                              "the HBM fraction above is kept for reference (traffic is far below algorithmic bytes where tables live in LDS)"}}
+            "issue": issue_bound(base_model, kms, plain_bytes, waves)}
+
+
+# Instructions the decoder wave of a block executes per plaintext byte on its hot path: static counts of the gfx950 ISA
+# (L1: the hand-written loop of zh_cm_fast.h; min / mid / max: zh_decode_c2_* from the EOS flag to the byte boundary's
+# last instruction, cold blocks excluded).  A lone wavefront issues at most one instruction per 4
+# cycles (tools/ubench/salu_bench), which is the ceiling the measured cycles per byte are set against.
+DECODER_INSTR_PER_BYTE = {"l1": 170, "min": 1000, "mid": 1650, "max": 3200}
+ISSUE_CYCLES_PER_INSTR = 4
+
+
+def issue_bound(base_model, kms, plain_bytes, waves):
+    cyc = kms * 1e-3 * CLOCK_GHZ * 1e9 / (plain_bytes / waves)
+    n = DECODER_INSTR_PER_BYTE.get(base_model)
+    return {"blocks_in_flight": waves,
+            "cycles_per_plain_byte_per_block": cyc,
+            "decoder_wave_instr_per_plain_byte": n,
+            "ceiling_cycles_per_instr": ISSUE_CYCLES_PER_INSTR,
+            "frac_of_issue_ceiling": (n * ISSUE_CYCLES_PER_INSTR / cyc) if n else None,
+            "note": "the operative bound is the dependent instruction chain of the wave that owns a block: the block's speed is "
+                    "(cycles per byte)^-1 and the floor is 4 cycles per instruction of that wave (static count); "
+                    "the HBM fraction above is kept for reference (traffic is far below algorithmic bytes where tables "
+                    "live in LDS, above them where the helper wave speculates over 16 candidate bytes)"}
 
 
 def resident_run(z, synth, torch, ctx, dev, model_name, kind, nb, bs, threads, cache_dir):
