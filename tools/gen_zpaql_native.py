@@ -41,9 +41,51 @@ def store(ddd: int, val: str) -> str:
     return f"H[d & hmask] = {val};"
 
 
-def translate(code: bytes, name: str) -> str:
-    """code = program bytes including the trailing END 0."""
+def reachable(code: bytes):
+    """Decode positions control can reach from pc 0 (a jump may land inside a 2-byte instruction, which ZPAQL defines
+    as decoding from there), in address order."""
     n = len(code)
+
+    def length(pc):
+        op = code[pc]
+        return 3 if op == 255 else 2 if op & 7 == 7 else 1
+
+    valid, work = set(), [0]
+    while work:
+        pc = work.pop()
+        if pc in valid or not 0 <= pc < n:
+            continue
+        valid.add(pc)
+        op = code[pc]
+        arg = code[pc + 1] if pc + 1 < n else 0
+        nxt = pc + length(pc)
+        if op in (39, 47):
+            work += [nxt, nxt + ((arg + 128) & 255) - 128]
+        elif op == 63:
+            work.append(nxt + ((arg + 128) & 255) - 128)
+        elif op == 255:
+            work.append(arg + 256 * (code[pc + 2] if pc + 2 < n else 0))
+        elif op == 56 or zpaql.is_error_op(op):
+            pass
+        else:
+            work.append(nxt)
+    return sorted(valid)
+
+
+def free_immediates(code: bytes):
+    """pcs of the reachable instructions whose second byte is a plain numeric operand (`a= N`, `a+= N`, `a> N` ...: not a
+    jump distance, not an R index) and is not itself a decode position: the bytes that vary between the programs the
+    reference generates from one template (LibZPAQ.cs:427-826) without changing their structure."""
+    valid = set(reachable(code))
+    return [pc for pc in sorted(valid) if code[pc] >= 64 and code[pc] != 255 and code[pc] & 7 == 7 and pc + 1 < len(code)
+            and pc + 1 not in valid]
+
+
+def translate(code: bytes, name: str, free=None) -> str:
+    """code = program bytes including the trailing END 0.  free: pcs whose numeric operand is read from the program at
+    run time (imm, one lane per operand) instead of being folded into the code."""
+    n = len(code)
+    free_ix = {pc: k for k, pc in enumerate(free or [])}
 
     def length(pc):
         op = code[pc]
@@ -84,7 +126,8 @@ def translate(code: bytes, name: str) -> str:
     out = [f"// {name}: {' '.join(zpaql.disassemble_code(code[:-1]))}",
            "template <class MP, class HP>",
            f"ZH_HD inline __attribute__((always_inline)) int zh_native_{name}(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, uint32_t &f, uint32_t input,",
-           "    MP M, uint32_t mmask, HP H, uint32_t hmask, uint32_t *R, zhcore::Sink *out, uint64_t budget) {",
+           "    MP M, uint32_t mmask, HP H, uint32_t hmask, uint32_t *R, zhcore::Sink *out, uint64_t budget"
+           + (", const ZhImm &imm) {" if free is not None else ") {"),
            "  a = zh_uni<MP>(input); b = zh_uni<MP>(b); c = zh_uni<MP>(c); d = zh_uni<MP>(d); f = zh_uni<MP>(f);",
            "  (void)R; (void)out; (void)budget; (void)f;"]
     for pc in starts:
@@ -126,7 +169,7 @@ def translate(code: bytes, name: str) -> str:
             tgt = code[pc + 1] + 256 * (code[pc + 2] if pc + 2 < n else 0)
             st = "return ZH_E_ZPAQL;" if tgt >= n else jump(tgt, pc)
         else:
-            s = SRC[op & 7] if op & 7 < 7 else f"{arg}u"
+            s = SRC[op & 7] if op & 7 < 7 else (f"zh_imm_get(imm, {free_ix[pc]}u)" if pc in free_ix else f"{arg}u")
             if op < 128:
                 ddd = (op >> 3) & 7
                 st = "return ZH_E_ZPAQL;" if ddd == 7 else store(ddd, s)
@@ -139,7 +182,7 @@ def translate(code: bytes, name: str) -> str:
     return "\n".join(out)
 
 
-def main():
+def render_native() -> str:
     progs = [("hcomp_min", models.get("min").header), ("hcomp_mid", models.get("mid").header),
              ("hcomp_max", models.get("max").header)]
     items = []
@@ -176,10 +219,104 @@ def main():
         lines.append(f"  if (zh_native_is_{name}(prog, len)) return ZH_NATIVE_{name.upper()};")
     lines.append("  return 0;")
     lines.append("}")
-    path = os.path.join(ROOT, "zpaqsharp_amd", "csrc", "zh_zpaql_native.h")
-    with open(path, "w") as f:
-        f.write("\n".join(lines) + "\n")
-    print("wrote", path)
+    return "\n".join(lines) + "\n"
+
+
+# Method strings that cover the structural variants of the reference's generated post-processors (LibZPAQ.cs:427-826):
+# lazy2 with / without the separate low offset bits (blocks > 16 MiB), lzpre, bwtrle for blocks up to / above 16 MiB,
+# each with and without the E8E9 pass, and E8E9 alone.  Other arguments only change numeric operands.
+PCOMP_SAMPLES = ["x0,1,4,0,3,16", "x6,1,4,0,3,24", "x0,5,4,0,3,16", "x6,5,4,0,3,24", "x0,2,12,0,7,16",
+                 "x0,6,5,0,3,16c0,0,511", "x0,3ci1", "x0,7ci1", "x5,3ci1", "x5,7ci1", "x0,4ci1"]
+
+
+def render_pcomp() -> str:
+    """zh_zpaql_pcomp.h: the post-processors, matched by STRUCTURE (opcodes, jumps, R indices, length) with their numeric
+    operands read from the program the block carries."""
+    from zpaqsharp_amd import methods
+    skel = []                                         # (name, code, free pcs, sample method)
+    seen = set()
+    for mt in PCOMP_SAMPLES:
+        code = methods.model_of(mt)[0].pcomp
+        free = free_immediates(code)
+        assert len(free) <= 64, (mt, len(free))
+        fixed = tuple(None if (i - 1) in free else code[i] for i in range(len(code)))
+        if fixed in seen:
+            continue
+        seen.add(fixed)
+        cmd = methods.make_config(mt)[0].split("pcomp", 1)[1].split()[0]
+        skel.append((f"pcomp_{cmd}_{len(code)}", code, free, mt))
+    L = ["// zh_zpaql_pcomp.h — GENERATED by tools/gen_zpaql_native.py from zpaqsharp_amd/methods.py; do not edit.",
+         "// Ahead-of-time translations of the reference's generated post-processors (lazy2, lzpre, bwtrle, e8e9:",
+         "// LibZPAQ.cs:427-826).  A block's PCOMP is matched by structure; its numeric operands (`a= N`, `a> N`, ...) are",
+         "// taken from the program it carries (ZhImm, filled when the program has been read).  Device only.",
+         "#pragma once", "#include <stdint.h>", "", '#include "zh_zpaql_native.h"', "",
+         "#pragma clang diagnostic push", '#pragma clang diagnostic ignored "-Wunused-label"', "",
+         "// The operands: wave-uniform values kept in vector registers (the kernels have hundreds to spare, and few scalar",
+         "// ones), made scalar where they are used.",
+         "struct ZhImm { uint32_t v[64]; };",
+         "__device__ inline __attribute__((always_inline)) uint32_t zh_imm_get(const ZhImm &m, uint32_t k) {",
+         "  return (uint32_t)__builtin_amdgcn_readfirstlane((int)m.v[k]);", "}",
+         "__device__ inline __attribute__((always_inline)) void zh_imm_set(ZhImm &m, uint32_t k, uint32_t val) { m.v[k] = val; }", ""]
+    for name, code, free, mt in skel:
+        L.append(f"// ---- {name}: e.g. method {mt}; {len(free)} operands")
+        L.append(translate(code, name, free).replace("ZH_HD inline", "__device__ inline"))
+        L.append("")
+    L.append("#pragma clang diagnostic pop")
+    L.append("")
+    for i, (name, code, free, mt) in enumerate(skel):
+        L.append(f"#define ZH_{name.upper()} {i + 1}u")
+    L.append("")
+    L.append("// Structure match.  Returns 0 when the program is not one of the above (it then runs on the interpreter).")
+    L.append("__device__ inline uint32_t zh_pcomp_lookup(const uint8_t *p, uint32_t len) {")
+    for name, code, free, mt in skel:
+        fr = set(pc + 1 for pc in free)
+        conds = [f"p[{i}] == {code[i]}" for i in range(len(code)) if i not in fr]
+        chunks = [" && ".join(conds[k:k + 8]) for k in range(0, len(conds), 8)]
+        L.append(f"  if (len == {len(code)}u &&\n      " + " &&\n      ".join(chunks) + f") return ZH_{name.upper()};")
+    L.append("  return 0;")
+    L.append("}")
+    L.append("// The operands of a matched program, written once (by the wave that has just read the program) to 64 words of LDS.")
+    L.append("__device__ inline void zh_pcomp_operands(uint32_t id, const uint8_t *p, uint32_t *words) {")
+    L.append("  for (int k = 0; k < 64; ++k) words[k] = 0;")
+    L.append("  switch (id) {")
+    for name, code, free, mt in skel:
+        L.append(f"    case ZH_{name.upper()}:")
+        for k, pc in enumerate(free):
+            L.append(f"      words[{k}] = p[{pc + 1}];")
+        L.append("      break;")
+    L.append("    default: break;")
+    L.append("  }")
+    L.append("}")
+    L.append("// One run of a matched program (PostProcessor.write in state 5, PostProcessor.cs:80-83).  A real call: the")
+    L.append("// translated programs stay out of the decoder loops' register allocation.  The machine registers travel by value.")
+    L.append("struct ZhPcRegs { uint32_t a, b, c, d, f; int rc; };")
+    L.append("__device__ __attribute__((noinline)) static ZhPcRegs zh_pcomp_call(uint32_t id, ZhPcRegs r, uint32_t input, uint8_t *M, uint32_t mmask,")
+    L.append("    uint32_t *H, uint32_t hmask, uint32_t *R, zhcore::Sink *out, uint64_t budget, const uint32_t *words) {")
+    L.append("  ZhImm imm;")
+    L.append("#pragma unroll")
+    L.append("  for (int k = 0; k < 16; ++k) {")
+    L.append("    const uint4 q = reinterpret_cast<const uint4 *>(words)[k];")
+    L.append("    imm.v[4 * k] = q.x; imm.v[4 * k + 1] = q.y; imm.v[4 * k + 2] = q.z; imm.v[4 * k + 3] = q.w;")
+    L.append("  }")
+    L.append("  switch (id) {")
+    for name, code, free, mt in skel:
+        L.append(f"    case ZH_{name.upper()}: r.rc = zh_native_{name}(r.a, r.b, r.c, r.d, r.f, input, M, mmask, H, hmask, R, out, budget, imm); break;")
+    L.append("    default: r.rc = ZH_E_ZPAQL; break;")
+    L.append("  }")
+    L.append("  return r;")
+    L.append("}")
+    return "\n".join(L) + "\n"
+
+
+OUTPUTS = {"zh_zpaql_native.h": render_native, "zh_zpaql_pcomp.h": render_pcomp}
+
+
+def main():
+    for name, fn in OUTPUTS.items():
+        path = os.path.join(ROOT, "zpaqsharp_amd", "csrc", name)
+        with open(path, "w") as f:
+            f.write(fn())
+        print("wrote", path)
 
 
 if __name__ == "__main__":

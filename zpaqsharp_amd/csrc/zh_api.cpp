@@ -22,7 +22,7 @@
 extern "C" hipError_t zh_launch_generic(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_sha1(const uint8_t *data, const uint64_t *seg, uint32_t n_seg, uint32_t *digest, hipStream_t stream);
-extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof);
+extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof, int pcall);
 extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_chain2(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof);
 extern "C" int zh_chain2_has(uint32_t spec);
@@ -362,7 +362,11 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, slots_of[g], stream));
     else if (g > ZH_FAM_CHAIN && zh_chain2_has(g - ZH_FAM_CHAIN) && opts.kernel != 5)   // per-model bit loop (zh_chain2.hip)
       HIPCHK(zh_launch_chain2(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));
-    else if (g >= ZH_FAM_CHAIN) HIPCHK(zh_launch_chain(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));
+    else if (g >= ZH_FAM_CHAIN) {
+      int pcall = 0;                                     // any model with PCOMP memory: the variant with translated post-processors
+      for (uint32_t k : groups[g]) pcall |= (models[bd[k].model].ph | models[bd[k].model].pm) != 0;
+      HIPCHK(zh_launch_chain(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof, pcall));
+    }
     else HIPCHK(zh_launch_generic(&L, slots_of[g], stream));
     ++launches;
     slots = std::max(slots, slots_of[g]);

@@ -28,6 +28,7 @@
 #include "zh_dev.h"
 #include "zh_model.h"
 #include "zh_zpaql_native.h"
+#include "zh_zpaql_pcomp.h"
 #define ZH_CHAIN_SPEC_DEVICE 1
 #include "zh_chain_spec.h"
 
@@ -62,6 +63,7 @@ struct alignas(16) ChainLds {
   uint8_t pmreg[kPMBytes];
   Vm hz, pz;
   Sink sink;
+  alignas(16) uint32_t pimm[64];          // operands of a structurally matched PCOMP (zh_zpaql_pcomp.h)
 };
 static_assert(sizeof(ChainLds) <= 163840, "LDS budget");
 
@@ -96,7 +98,7 @@ struct Lane {
   bool rowvalid;                          // slot holds a row/line that must be written back
 };
 
-template <bool PROF, class SP>
+template <bool PROF, class SP, bool PCALL>
 __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S) {
   constexpr bool kSpec = SP::id != 0;
   constexpr bool kDefer = SP::id == 1 || SP::id == 2;   // deferred mixer-weight store (measured: helps min / mid, not max)
@@ -295,6 +297,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
     pz.r = S.pr;
     const bool p_lds = pz.m == S.pmreg && pz.h == S.phreg;
     uint32_t pnative = 0;                                 // set when the loaded PCOMP is a known program
+    uint32_t pskel = 0;                                   // ... or has the structure of one of the reference's generated ones (zh_zpaql_pcomp.h)
     uint32_t pa = 0, pb = 0, pc_ = 0, pd = 0, pf = 0;
     uint8_t *pzbuf = slot_mem + uni64(M->pz_off) + ZH_CODE_PAD;
 
@@ -676,6 +679,12 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
           int rc;
           if (pnative == ZH_NATIVE_PCOMP_E8E9)
             rc = zh_native_pcomp_e8e9(pa, pb, pc_, pd, pf, (uint32_t)c, (lds_u8_p)lds_off(S.pmreg), pz.mmask, (lds_u32_p)lds_off(S.phreg), pz.hmask, S.pr, &sink, L.budget);
+          else if (PCALL && pskel) {
+            ZhPcRegs r{pa, pb, pc_, pd, pf, 0};
+            r = zh_pcomp_call(pskel, r, (uint32_t)c, pz.m, pz.mmask, pz.h, pz.hmask, S.pr, &sink, L.budget, S.pimm);
+            pa = r.a; pb = r.b; pc_ = r.c; pd = r.d; pf = r.f;
+            rc = r.rc;
+          }
           else rc = vm_run(pz, (uint32_t)c, &sink, L.budget);
           rc = (int)uni((uint32_t)rc);
           if (rc) { status = rc; break; }
@@ -699,6 +708,11 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             pz.prog = pzbuf; pz.len = pp_len;
             pz.a = pz.b = pz.c = pz.d = pz.f = 0;
             pnative = p_lds ? uni(zh_native_lookup(pzbuf, pp_len)) : 0;
+            if constexpr (PCALL) {
+              pskel = pnative ? 0u : uni(zh_pcomp_lookup(pzbuf, pp_len));
+              if (lane == 0) zh_pcomp_operands(pskel, pzbuf, S.pimm);
+              __syncthreads();
+            }
             pp_state = 5;
           }
         }
@@ -727,24 +741,30 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
 
 #undef ZH_HAS
 
-#define ZH_CHAIN_KERNEL(name, prof, spec)                                              \
+#define ZH_CHAIN_KERNEL(name, prof, spec, pcall)                                       \
   extern "C" __global__ __launch_bounds__(64) void name(ZhLaunch L) {                  \
     __shared__ ChainLds S;                                                             \
-    decode_chain_body<prof, spec>(L, S);                                               \
+    decode_chain_body<prof, spec, pcall>(L, S);                                        \
   }
-ZH_CHAIN_KERNEL(zh_decode_chain, false, ZhSpec_generic)
-ZH_CHAIN_KERNEL(zh_decode_chain_min, false, ZhSpec_min)
-ZH_CHAIN_KERNEL(zh_decode_chain_mid, false, ZhSpec_mid)
-ZH_CHAIN_KERNEL(zh_decode_chain_max, false, ZhSpec_max)
-ZH_CHAIN_KERNEL(zh_decode_chain_prof, true, ZhSpec_generic)
-ZH_CHAIN_KERNEL(zh_decode_chain_mid_prof, true, ZhSpec_mid)
-ZH_CHAIN_KERNEL(zh_decode_chain_max_prof, true, ZhSpec_max)
+ZH_CHAIN_KERNEL(zh_decode_chain, false, ZhSpec_generic, false)
+// ... the same with the translated post-processors of zh_zpaql_pcomp.h behind a call: launched for models that give their
+// PCOMP memory (ph or pm > 0: lazy2, lzpre, bwtrle).  Kept apart because the mere presence of a call costs the bit loop
+// ~10 % (scalar registers reserved for the stack), which blocks without such a post-processor should not pay.
+ZH_CHAIN_KERNEL(zh_decode_chain_pc, false, ZhSpec_generic, true)
+ZH_CHAIN_KERNEL(zh_decode_chain_min, false, ZhSpec_min, false)
+ZH_CHAIN_KERNEL(zh_decode_chain_mid, false, ZhSpec_mid, false)
+ZH_CHAIN_KERNEL(zh_decode_chain_max, false, ZhSpec_max, false)
+ZH_CHAIN_KERNEL(zh_decode_chain_prof, true, ZhSpec_generic, false)
+ZH_CHAIN_KERNEL(zh_decode_chain_mid_prof, true, ZhSpec_mid, false)
+ZH_CHAIN_KERNEL(zh_decode_chain_max_prof, true, ZhSpec_max, false)
 
-// spec: 0 generic, 1 min, 2 mid, 3 max (zh_chain_spec.h); prof: diagnostic build with stamps
-extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof) {
+// spec: 0 generic, 1 min, 2 mid, 3 max (zh_chain_spec.h); prof: diagnostic build with stamps; pcall: some model of the
+// launch has PCOMP memory
+extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof, int pcall) {
   void (*k)(ZhLaunch) = zh_decode_chain;
   if (prof) k = spec == 2 ? zh_decode_chain_mid_prof : spec == 3 ? zh_decode_chain_max_prof : zh_decode_chain_prof;
-  else k = spec == 1 ? zh_decode_chain_min : spec == 2 ? zh_decode_chain_mid : spec == 3 ? zh_decode_chain_max : zh_decode_chain;
+  else k = spec == 1 ? zh_decode_chain_min : spec == 2 ? zh_decode_chain_mid : spec == 3 ? zh_decode_chain_max
+           : pcall ? zh_decode_chain_pc : zh_decode_chain;
   hipLaunchKernelGGL(k, dim3(grid), dim3(64), 0, stream, *L);
   return hipGetLastError();
 }

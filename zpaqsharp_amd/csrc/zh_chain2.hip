@@ -293,7 +293,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
       const ZhComp &mc = M->comp[SP::mix_lane[q]];
       mx_base[q] = uni((uint32_t)mc.cm_off); mx_size1[q] = uni(mc.cm_mask);
     }
-    uint32_t ha = 0, hb = 0, hc = 0, hd = 0, hf = 0;      // committed HCOMP registers (M and H: S.mreg / S.hreg, zeroed by A)
+    uint32_t hb = 0, hc = 0, hd = 0, hf = 0;              // committed HCOMP registers (A is the input at every run; M and H: S.mreg / S.hreg, zeroed by A)
     c2_put0(&S.mb_ack, cmd);
     uint32_t seq = 1;
     bool alive = true;
@@ -394,7 +394,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
       }
       if (!alive) break;
       const uint32_t lo = v & 15u;
-      ha = rdlane(sa, lo); hb = rdlane(sb, lo); hc = rdlane(sc, lo); hd = rdlane(sd, lo); hf = rdlane(sf, lo);
+      hb = rdlane(sb, lo); hc = rdlane(sc, lo); hd = rdlane(sd, lo); hf = rdlane(sf, lo);
       const uint32_t cwi = rdlane(wi, lo), cwv = rdlane(wv, lo), cwn = rdlane(wn, lo);
       if (cwn && lane == 0) S.mreg[cwi] = (uint8_t)cwv;
       if (lane < NH) { const uint32_t hv_ = S.hspec[lane][lo]; S.hreg[lane] = hv_; }
@@ -588,7 +588,6 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     MRegs<kMRegs> mregs;
     for (int i = 0; i < kMRegs; ++i) mregs.v[i] = 0;
     const MView<kMRegs> reg_m{&mregs};                   // M of the native programs (hm <= 8 + log2 kMRegs, checked by the host)
-    const lds_u8_p lds_m = (lds_u8_p)lds_off(S.mreg);
     const lds_u32_p lds_h = (lds_u32_p)lds_off(S.hreg);
 
     int pp_state = 0, pp_hsize = 0;                    // PostProcessor (PostProcessor.cs:12-16)

@@ -22,15 +22,7 @@ struct alignas(16) ZhRow16 { uint32_t w[4]; };
 
 struct CompSt { uint32_t limit, cxt, a, b, c; };   // Component.cs:20-22
 
-struct alignas(16) GenLds {
-  ZhTables t;
-  int32_t p[256];
-  uint32_t h[256];
-  uint32_t r[256];     // HCOMP R
-  uint32_t pr[256];    // PCOMP R
-  CompSt cs[256];
-  ZhComp cd[ZH_MAX_LDS_COMP];
-};
+
 
 struct Sink {          // Writer for one block (ZPAQL.outc/flush, ZPAQL.cs:194-207)
   uint8_t *out;
@@ -40,6 +32,18 @@ ZH_HD inline void sink_put(Sink &s, uint32_t c) {
   if (s.len < s.cap) s.out[s.len] = (uint8_t)c;
   ++s.len;
 }
+
+struct alignas(16) GenLds {
+  ZhTables t;
+  int32_t p[256];
+  uint32_t h[256];
+  uint32_t r[256];     // HCOMP R
+  uint32_t pr[256];    // PCOMP R
+  CompSt cs[256];
+  ZhComp cd[ZH_MAX_LDS_COMP];
+  alignas(16) uint32_t pimm[64];   // operands of a structurally matched PCOMP (zh_zpaql_pcomp.h)
+  Sink sink;                       // the block's Writer (in LDS: the translated PCOMPs are real calls and take its address)
+};
 
 struct Src {           // Reader over one segment's coded bytes (Decoder.get, Decoder.cs:112-122)
   const uint8_t *p, *end;

@@ -17,6 +17,7 @@
 
 #include "zh_core.h"
 #include "zh_model.h"
+#include "zh_zpaql_pcomp.h"
 
 using namespace zhcore;
 
@@ -45,11 +46,12 @@ __device__ __forceinline__ int decode_bit(Coder &d, Src &in, uint32_t p) {
 struct PostProc {      // PostProcessor.cs:12-16
   int state, hsize;
   uint32_t plen;       // PCOMP bytes loaded so far
+  uint32_t native;     // zh_zpaql_pcomp.h: ahead-of-time translation of the loaded program, 0 = interpret
   Vm z;
 };
 
 // PostProcessor.cs:37-86.  c is 0..255 or -1.  Returns 0 or a status.
-__device__ int pp_write(PostProc &pp, int c, Sink &out, const ZhModel *M, uint8_t *slot, uint64_t budget) {
+__device__ int pp_write(PostProc &pp, int c, Sink &out, const ZhModel *M, uint8_t *slot, uint64_t budget, uint32_t *pimm) {
   switch (pp.state) {
     case 0:
       if (c < 0) return ZH_E_PP_EOS;
@@ -80,11 +82,19 @@ __device__ int pp_write(PostProc &pp, int c, Sink &out, const ZhModel *M, uint8_
         pp.z.prog = buf;
         pp.z.len = pp.plen;
         pp.z.a = pp.z.b = pp.z.c = pp.z.d = pp.z.f = 0;
+        pp.native = zh_pcomp_lookup(buf, pp.plen);
+        zh_pcomp_operands(pp.native, buf, pimm);
         pp.state = 5;
       }
       break;
     }
     default:
+      if (pp.native) {
+        ZhPcRegs r{pp.z.a, pp.z.b, pp.z.c, pp.z.d, pp.z.f, 0};
+        r = zh_pcomp_call(pp.native, r, (uint32_t)c, pp.z.m, pp.z.mmask, pp.z.h, pp.z.hmask, pp.z.r, &out, budget, pimm);
+        pp.z.a = r.a; pp.z.b = r.b; pp.z.c = r.c; pp.z.d = r.d; pp.z.f = r.f;
+        return r.rc;
+      }
       return vm_run(pp.z, (uint32_t)c, &out, budget);
   }
   return 0;
@@ -249,14 +259,14 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_generic(ZhLaunch L) {
       if (n) { d.low = 1; d.high = 0xFFFFFFFFu; d.curr = 0; }
       else d.low = d.high = d.curr = 0;
       PostProc pp;
-      pp.state = 0; pp.hsize = 0; pp.plen = 0;
+      pp.state = 0; pp.hsize = 0; pp.plen = 0; pp.native = 0;
       pp.z.a = pp.z.b = pp.z.c = pp.z.d = pp.z.f = 0;
       pp.z.prog = nullptr; pp.z.len = 0;
       pp.z.m = slot + M->pm_off; pp.z.mmask = (uint32_t)((1ull << M->pm) - 1);
       pp.z.h = (uint32_t *)(slot + M->ph_off); pp.z.hmask = (uint32_t)((1ull << M->ph) - 1);
       pp.z.r = S.pr;
 
-      Sink out;
+      Sink &out = S.sink;
       out.out = L.out + bd.out_off; out.cap = bd.out_cap; out.len = 0;
 
       int failed = 0;
@@ -279,7 +289,7 @@ extern "C" __global__ __launch_bounds__(64) void zh_decode_generic(ZhLaunch L) {
         for (;;) {                                     // Decompresser.decompress(-1), Decompresser.cs:121-153
           int c = decode_byte(P, d, in, L.budget);
           if (c < -1) { status = c + 100; break; }
-          int rc = pp_write(pp, c, out, M, slot, L.budget);
+          int rc = pp_write(pp, c, out, M, slot, L.budget, S.pimm);
           if (rc) { status = rc; break; }
           if (c == -1) break;
           if ((L.flags & ZH_LAUNCH_PP_ONLY) && (pp.state == 1 || pp.state == 5)) { status = ZH_E_STOPPED; break; }   // pcomp() read-back

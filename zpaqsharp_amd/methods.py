@@ -702,14 +702,17 @@ def preprocess(data: bytes, args: List[int]) -> bytes:
     return d
 
 
-def compress_block(method: str, data: bytes, filename: bytes = b"") -> bytes:
+def compress_block(method: str, data: bytes, filename: bytes = b"", pre: bytes = None) -> bytes:
     """One block the way LibZPAQ.compressBlock frames it (tag, header, segment with the size as comment, SHA-1), coded by
-    this repo's CPU stream writer; n = 0 models (methods like "x0,1,4,0,3,24") use the unmodelled store layout."""
+    this repo's CPU stream writer; n = 0 models (methods like "x0,1,4,0,3,24") use the unmodelled store layout.
+    `pre`: bytes to feed the post-processor instead of preprocess(data) (tests of the PCOMP programs on input no
+    encoder writes; the size comment and SHA-1 still describe `data`)."""
     import hashlib
 
     from . import synth
     model, args = model_of(method)
-    pre = preprocess(data, args)
+    if pre is None:
+        pre = preprocess(data, args)
     if model.n:
         return synth.compress_block(model, np.frombuffer(data, np.uint8) if data else np.zeros(0, np.uint8), filename=filename,
                                     pre=np.frombuffer(pre, np.uint8) if pre else np.zeros(0, np.uint8))
