@@ -123,6 +123,11 @@ def translate(code: bytes, name: str, free=None) -> str:
         pre = "if (budget-- == 0) return ZH_E_BUDGET; " if target <= back_from else ""
         return f"{pre}goto L{target};"
 
+    # R registers the program names (constant indices): in the post-processor form they live in locals for the run —
+    # read at entry, the written ones stored back at every exit — instead of an LDS round trip per `a=r N` / `r=a N`.
+    r_read = sorted({code[pc + 1] for pc in starts if code[pc] < 64 and code[pc] & 7 == 7 and (code[pc] >> 3) < 4 and pc + 1 < n})
+    r_written = sorted({code[pc + 1] for pc in starts if code[pc] < 64 and code[pc] & 7 == 7 and (code[pc] >> 3) == 6 and pc + 1 < n})
+    r_local = free is not None
     out = [f"// {name}: {' '.join(zpaql.disassemble_code(code[:-1]))}",
            "template <class MP, class HP>",
            f"ZH_HD inline __attribute__((always_inline)) int zh_native_{name}(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, uint32_t &f, uint32_t input,",
@@ -130,6 +135,11 @@ def translate(code: bytes, name: str, free=None) -> str:
            + (", const ZhImm &imm) {" if free is not None else ") {"),
            "  a = zh_uni<MP>(input); b = zh_uni<MP>(b); c = zh_uni<MP>(c); d = zh_uni<MP>(d); f = zh_uni<MP>(f);",
            "  (void)R; (void)out; (void)budget; (void)f;"]
+    if r_local:
+        for k in sorted(set(r_read) | set(r_written)):
+            out.append(f"  uint32_t R{k} = zh_uni<MP>(R[{k}]);")
+        out.append("  int rc_ = 0;")
+        out.append("  zhcore::Sink sk_ = *out;                        // the Writer's cursor in registers for the run (out is never null for a PCOMP)")
     for pc in starts:
         op = code[pc]
         arg = code[pc + 1] if pc + 1 < n else 0
@@ -140,13 +150,13 @@ def translate(code: bytes, name: str, free=None) -> str:
             if x == 7:
                 off = ((arg + 128) & 255) - 128
                 if ddd < 4:
-                    st = f"{'abcd'[ddd]} = zh_uni<MP>(R[{arg}]);"
+                    st = f"{'abcd'[ddd]} = R{arg};" if r_local else f"{'abcd'[ddd]} = zh_uni<MP>(R[{arg}]);"
                 elif ddd == 4:
                     st = f"if (f) {{ {jump(nxt + off, pc)} }}"
                 elif ddd == 5:
                     st = f"if (!f) {{ {jump(nxt + off, pc)} }}"
                 elif ddd == 6:
-                    st = f"R[{arg}] = a;"
+                    st = f"R{arg} = a;" if r_local else f"R[{arg}] = a;"
                 else:
                     st = jump(nxt + off, pc)
             elif ddd == 7:
@@ -178,6 +188,15 @@ def translate(code: bytes, name: str, free=None) -> str:
                 st = ALU[k].format(s=s) if k < 14 else "return ZH_E_ZPAQL;"
         fall = "" if (st.startswith("return") or st.startswith("goto") or st.startswith("if (budget")) else f" {jump(nxt, -1)}"
         out.append(f"  L{pc}: {st}{fall}  // {zpaql.OPCODES[op] or 'error'}")
+    if r_local:
+        import re
+        out = [re.sub(r"return ([A-Za-z0-9_]+);", r"{ rc_ = \1; goto Lexit; }", ln) if ln.startswith("  L") else ln for ln in out]
+        out = [ln.replace("if (out) zhcore::sink_put(*out, a & 255);", "zhcore::sink_put(sk_, a & 255);") for ln in out]
+        out.append("  Lexit:")
+        out.append("  out->len = sk_.len;")
+        for k in r_written:
+            out.append(f"  R[{k}] = R{k};")
+        out.append("  return rc_;")
     out.append("}")
     return "\n".join(out)
 
@@ -294,7 +313,7 @@ def render_pcomp() -> str:
     L.append("    uint32_t *H, uint32_t hmask, uint32_t *R, zhcore::Sink *out, uint64_t budget, const uint32_t *words) {")
     L.append("  ZhImm imm;")
     L.append("#pragma unroll")
-    L.append("  for (int k = 0; k < 16; ++k) {")
+    L.append("  for (int k = 0; k < 16; ++k) {                   // (all 64 words: the programs' operand counts differ little)")
     L.append("    const uint4 q = reinterpret_cast<const uint4 *>(words)[k];")
     L.append("    imm.v[4 * k] = q.x; imm.v[4 * k + 1] = q.y; imm.v[4 * k + 2] = q.z; imm.v[4 * k + 3] = q.w;")
     L.append("  }")
