@@ -154,6 +154,28 @@ def issue_bound(base_model, kms, plain_bytes, waves):
                     "live in LDS, above them where the helper wave speculates over 16 candidate bytes)"}
 
 
+def method_streams(z, synth, ctx, kib=64, blocks=256):
+    """The widened row: streams written with the reference's LZ77 method strings, whose cost is the
+    post-processor (zh_zpaql_pcomp.h).  One block per method, replicated (identical blocks decode independently);
+    host buffer to host buffer, checked against the plaintext."""
+    import time
+    from zpaqsharp_amd import methods
+    plain = synth.plain("T", 7, kib << 10).tobytes()
+    out = []
+    for mt, what in (("x0,1,4,0,3,16", "lazy2: bit-packed LZ77, no model"), ("x0,2,12,0,7,16", "lzpre: byte-aligned LZ77, no model"),
+                     ("x0,5,4,0,3,16", "lazy2 + E8E9")):
+        s = methods.compress_block(mt, plain) * blocks
+        got = ctx.decompress(s)                                   # warm-up: arena allocation
+        ok = got.size == len(plain) * blocks and got[:len(plain)].tobytes() == plain and got[-len(plain):].tobytes() == plain
+        t0 = time.time()
+        ctx.decompress(s)
+        dt = time.time() - t0
+        out.append({"method": mt, "what": what, "workload": f"{blocks} x {kib} KiB blocks (one block replicated), text-like plaintext",
+                    "value": (len(plain) * blocks / dt / 1e6) if ok else 0.0, "unit": "MB/s (host to host)",
+                    "kernel_ms": float(ctx.stats().kernel_ms), "bit_exact": bool(ok)})
+    return out
+
+
 def resident_run(z, synth, torch, ctx, dev, model_name, kind, nb, bs, threads, cache_dir):
     """One GPU, one decode pass over a resident stream: (MB/s, kernel_ms, rho, bit_exact, stats)."""
     from zpaqsharp_amd import models
@@ -340,6 +362,7 @@ def main():
                                    "full-size runs: profiles/)"),
                     "value": v if okx else 0.0, "unit": "MB/s", "bit_exact": bool(okx), "kernel_kind": int(sx.kernel_kind),
                     "roofline": roofline(mname.split("+")[0], k, 256 * ebs, r, 256, ebs, mname)})
+            extras["method_streams"] = method_streams(z, synth, ctx)
 
     line = {
         "metric": "decompress MB/s (bit-exact) on 1 GiB multi-block stream",
