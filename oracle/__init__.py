@@ -129,6 +129,11 @@ def tag_hash(data: bytes) -> Tuple[int, int, int, int]:
     return tuple(h)
 
 
+def set_zpaql_budget(per_run: int) -> None:
+    """Test guard: instructions one ZPAQL run() may execute (0 = unlimited, the reference's behaviour)."""
+    lib().zo_set_zpaql_budget(C.c_uint64(per_run))
+
+
 def decompress(stream: bytes, cap: Optional[int] = None) -> bytes:
     """LibZPAQ.decompress(Reader, Writer) on the oracle."""
     import numpy as np

@@ -337,11 +337,22 @@ static inline void vm_outc(vm_t *z, int ch) {
 /* ZPAQL.cs:1028-1251 execute(), 1253-1265 run0(), 1267-1303 div/mod/swap.
  * Written from the ISA description (ZPAQL.cs:238-321) as a decode of the
  * opcode fields rather than a 256-way case list. */
+/* Test guard, not reference behaviour: instructions one run() may execute (0 = unlimited, as in the reference).  A
+ * post-processor fed bytes no encoder writes need not terminate (bwtrle's list traversal on a garbage BWT index); the
+ * device bounds every run with zpaqhip_opts.zpaql_budget, and the arbitrary-input tests bound the oracle likewise. */
+static U64 g_vm_budget = 0;
+void zo_set_zpaql_budget(U64 per_run) { g_vm_budget = per_run; }
+
 static void vm_run(vm_t *z, U32 input) {
   const U8 *hd = z->header;
   int pc = z->hbegin;
   U32 a = input, b = z->b, c = z->c, d = z->d; int f = z->f;
+  U64 left = g_vm_budget ? g_vm_budget : ~(U64)0;
   for (;;) {
+    if (left-- == 0) {
+      z->a = a; z->b = b; z->c = c; z->d = d; z->f = f; z->pc = pc;
+      zerror(z->err, "ZPAQL instruction budget exhausted");
+    }
     int op = hd[pc++];
     if (op < 64) {
       int ddd = op >> 3, x = op & 7;

@@ -86,6 +86,9 @@ int zo_enc_end_block(zo_enc *);
 /* ---- helpers ----------------------------------------------------------- */
 void zo_sha1(const uint8_t *p, size_t n, uint8_t out[20]);
 void zo_e8e9(uint8_t *buf, size_t n);                 /* LibZPAQ.cs:372-384 */
+/* Test guard (not reference behaviour): ZPAQL instructions one run() may execute before the oracle reports
+ * "ZPAQL instruction budget exhausted"; 0 = unlimited. */
+void zo_set_zpaql_budget(uint64_t per_run);
 /* Runs a ZPAQL program stand-alone as PCOMP: feeds in[0..n) then EOF. */
 long zo_run_pcomp(const uint8_t *pcomp, size_t plen, int ph, int pm,
                   const uint8_t *in, size_t n, uint8_t *out, size_t cap);
