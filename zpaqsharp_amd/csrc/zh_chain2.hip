@@ -45,6 +45,7 @@ struct C2Min {                               // 0 icm 16 ; 1 isse 19 0
   static constexpr uint64_t icm = 0x1, isse = 0x2;
   static constexpr int helper = 1;            // helper wave: HCOMP, hash rows and mixer rows of the next byte
   static constexpr bool smem_ps = false;
+  static constexpr bool guard_rows = true;    // boundary: patch candidate rows behind one wave-level test (same-box A/B: +1.6 %)
   static constexpr int match_lane = -1;
   static constexpr uint32_t mix_lane[2] = {0, 0}, mix_j0[2] = {0, 0}, mix_m[2] = {0, 0};
   static constexpr bool has_tail = false;
@@ -54,6 +55,7 @@ struct C2Mid {                               // 0 icm ; 1-5 isse ; 6 match ; 7 m
   static constexpr uint64_t icm = 0x01, isse = 0x3e;
   static constexpr int helper = 1;            // helper wave: HCOMP, hash rows and mixer rows of the next byte
   static constexpr bool smem_ps = true;
+  static constexpr bool guard_rows = false;   // ... here the test's taken branch costs more than the selects it skips (-1.5 %)
   static constexpr int match_lane = 6;
   static constexpr uint32_t mix_lane[2] = {7, 0}, mix_j0[2] = {0, 0}, mix_m[2] = {7, 0};
   static constexpr bool has_tail = false;
@@ -65,8 +67,9 @@ struct C2Max {                               // Compressor.cs:60-72: 0 const; 1 
                                              // 15 mix 16 0 15 24 255; 16 mix 8 0 16 10 255; 17 mix2 0 15 16 24 0; 18 sse 8 17 32 255;
                                              // 19 mix2 8 17 18 16 255; 20 sse 16 19 32 255; 21 mix2 0 19 20 16 0
   static constexpr uint32_t id = 3, n = 22, depth = 6, final_lane = 21, nmix = 2, hh = 5, hm = 9;
-  static constexpr int helper = 2;            // helper wave: HCOMP only (LDS has no room for staged rows)
+  static constexpr int helper = 2;            // helper wave: HCOMP, and the lines of the next byte's rows touched (no LDS left to stage them)
   static constexpr bool smem_ps = false;
+  static constexpr bool guard_rows = false;
   static constexpr uint64_t icm = (1u << 1) | (1u << 9) | (1u << 11) | (1u << 12) | (1u << 13) | (1u << 14), isse = 0xfcu | (1u << 10);
   static constexpr int match_lane = 8;
   static constexpr uint32_t mix_lane[2] = {15, 16}, mix_j0[2] = {0, 0}, mix_m[2] = {15, 16};
@@ -1089,7 +1092,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
                 cm_pre = __builtin_amdgcn_raw_buffer_load_b32(rsrc, l_match ? cmo + (hv & cm_mask) * 4u : kOob, 0, 0);
               }
               C2_STAMP(6);
-              rows_finish2(pr, old1, old1_off, old1_valid, old, old_off, old_valid, true);
+              rows_finish2(pr, old1, old1_off, old1_valid, old, old_off, old_valid, SP::guard_rows);
               asm volatile("" ::: "memory");
               C2_STAMP(7);
             } else {
