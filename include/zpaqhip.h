@@ -118,7 +118,9 @@ typedef struct zpaqhip_opts {
   uint32_t kernel;            /* 0 auto; 1 force the generic (one-lane) kernel; 3 prefer the lane-per-component kernel;
                                  4 lane-per-component without model specialisation; 5 the run-time-level form of the
                                  lane-per-component kernel also for the built-in min/mid/max models (cross-check) */
-  uint64_t zpaql_budget;      /* max ZPAQL instructions per run() call; 0 = default (1<<32) */
+  uint64_t zpaql_budget;      /* runaway-program guard, per run() call: max ZPAQL instructions on the interpreter, max backward
+                                 jumps in an ahead-of-time translated program (a translation checks where it can loop);
+                                 0 = default (1<<32).  Exceeding it ends the block with ZPAQHIP_E_BUDGET */
   uint64_t batch_blocks;      /* whole-stream forms: blocks per pipeline batch; 0 = default (at least 256 blocks and 32 MiB
                                  of coded bytes per batch, so that every CU has a block) */
   uint64_t reserved[3];
