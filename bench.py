@@ -159,7 +159,7 @@ def method_streams(z, synth, ctx, kib=64, blocks=256):
     post-processor (zh_zpaql_pcomp.h).  One block per method, replicated (identical blocks decode independently);
     host buffer to host buffer, checked against the plaintext."""
     import time
-    from zpaqsharp_amd import methods
+    from tools import methods
     plain = synth.plain("T", 7, kib << 10).tobytes()
     out = []
     for mt, what in (("x0,1,4,0,3,16", "lazy2: bit-packed LZ77, no model"), ("x0,2,12,0,7,16", "lzpre: byte-aligned LZ77, no model"),

@@ -8,7 +8,8 @@ import pytest
 import oracle
 import zpaqsharp_amd as z
 from tests import util
-from zpaqsharp_amd import methods, zpaql
+from tools import methods
+from zpaqsharp_amd import zpaql
 
 METHODS = [
     "x0,1,4,0,3,16",                 # level 1: lazy2, bit-packed LZ77, no model (n = 0: stored)      LibZPAQ.cs:427-572

@@ -251,7 +251,7 @@ PCOMP_SAMPLES = ["x0,1,4,0,3,16", "x6,1,4,0,3,24", "x0,5,4,0,3,16", "x6,5,4,0,3,
 def render_pcomp() -> str:
     """zh_zpaql_pcomp.h: the post-processors, matched by STRUCTURE (opcodes, jumps, R indices, length) with their numeric
     operands read from the program the block carries."""
-    from zpaqsharp_amd import methods
+    from tools import methods
     skel = []                                         # (name, code, free pcs, sample method)
     seen = set()
     for mt in PCOMP_SAMPLES:
@@ -264,7 +264,7 @@ def render_pcomp() -> str:
         seen.add(fixed)
         cmd = methods.make_config(mt)[0].split("pcomp", 1)[1].split()[0]
         skel.append((f"pcomp_{cmd}_{len(code)}", code, free, mt))
-    L = ["// zh_zpaql_pcomp.h — GENERATED by tools/gen_zpaql_native.py from zpaqsharp_amd/methods.py; do not edit.",
+    L = ["// zh_zpaql_pcomp.h — GENERATED by tools/gen_zpaql_native.py from tools/methods.py; do not edit.",
          "// Ahead-of-time translations of the reference's generated post-processors (lazy2, lzpre, bwtrle, e8e9:",
          "// LibZPAQ.cs:427-826).  A block's PCOMP is matched by structure; its numeric operands (`a= N`, `a> N`, ...) are",
          "// taken from the program it carries (ZhImm, filled when the program has been read).  Device only.",

@@ -18,7 +18,8 @@ def main():
     ap.add_argument("--methods", default="x0,1,4,0,3,16;x0,2,12,0,7,16;x0,3ci1;x0,5,4,0,3,16")
     a = ap.parse_args()
     import zpaqsharp_amd as z
-    from zpaqsharp_amd import methods, synth
+    from tools import methods
+    from zpaqsharp_amd import synth
     ctx = z.Context(0)
     plain = synth.plain("T", 7, a.kib << 10).tobytes()
     for mt in a.methods.split(";"):

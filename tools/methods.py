@@ -22,7 +22,7 @@ from typing import List, Tuple
 
 import numpy as np
 
-from . import zpaql
+from zpaqsharp_amd import zpaql
 
 
 def _lg(x: int) -> int:
@@ -53,11 +53,11 @@ def parse_args(method: str) -> Tuple[str, List[int], str]:
 
 
 _E8E9_TAIL = """
-    d=b b=0 do (for b=0..d-1, d = end of buf)
+    d=b b=0 do
       a=b a==d ifnot
         a+= 4 a<d if
-          a=*b a&= 254 a== 232 if (e8 or e9?)
-            c=b b++ b++ b++ b++ a=*b a++ a&= 254 a== 0 if (00 or ff)
+          a=*b a&= 254 a== 232 if
+            c=b b++ b++ b++ b++ a=*b a++ a&= 254 a== 0 if
               b-- a=*b
               b-- a<<= 8 a+=*b
               b-- a<<= 8 a+=*b
@@ -79,122 +79,107 @@ def _pcomp_lazy2(args: List[int], doe8: bool) -> str:
     """LibZPAQ.cs:427-572."""
     rb = args[0] - 4 if args[0] > 4 else 0
     p = """pcomp lazy2 3 ;
- (r1 = state
-  r2 = len - match or literal length
-  r3 = m - number of offset bits expected
-  r4 = ptr to buf
-  r5 = r - low bits of offset
-  c = bits - input buffer
-  d = n - number of bits in c)
 
   a> 255 if
 """
     if doe8:
         p += _E8E9_TAIL.replace("    d=b b=0 do", "    b=0 d=r 4 do")
     p += """
-    (reset state)
     a=0 b=0 c=0 d=0 r=a 1 r=a 2 r=a 3 r=a 4
     halt
   endif
 
-  a<<=d a+=c c=a               (bits+=a<<n)
-  a= 8 a+=d d=a                (n+=8)
+  a<<=d a+=c c=a
+  a= 8 a+=d d=a
 
-  (if state==0 (expect new code))
-  a=r 1 a== 0 if (match code mm,mmm)
-    a= 1 r=a 2                 (len=1)
-    a=c a&= 3 a> 0 if          (if (bits&3))
-      a-- a<<= 3 r=a 3           (m=((bits&3)-1)*8)
-      a=c a>>= 2 c=a             (bits>>=2)
-      b=r 3 a&= 7 a+=b r=a 3     (m+=bits&7)
-      a=c a>>= 3 c=a             (bits>>=3)
-      a=d a-= 5 d=a              (n-=5)
-      a= 1 r=a 1                 (state=1)
-    else (literal, discard 00)
-      a=c a>>= 2 c=a             (bits>>=2)
-      d-- d--                    (n-=2)
-      a= 3 r=a 1                 (state=3)
+  a=r 1 a== 0 if
+    a= 1 r=a 2
+    a=c a&= 3 a> 0 if
+      a-- a<<= 3 r=a 3
+      a=c a>>= 2 c=a
+      b=r 3 a&= 7 a+=b r=a 3
+      a=c a>>= 3 c=a
+      a=d a-= 5 d=a
+      a= 1 r=a 1
+    else
+      a=c a>>= 2 c=a
+      d-- d--
+      a= 3 r=a 1
     endif
   endif
 
-  (while state==1 && n>=3 (expect match length n*4+ll . r2))
   do a=r 1 a== 1 if a=d a> 2 if
-    a=c a&= 1 a== 1 if         (if bits&1)
-      a=c a>>= 1 c=a             (bits>>=1)
-      b=r 2 a=c a&= 1 a+=b a+=b r=a 2 (len+=len+(bits&1))
-      a=c a>>= 1 c=a             (bits>>=1)
-      d-- d--                    (n-=2)
+    a=c a&= 1 a== 1 if
+      a=c a>>= 1 c=a
+      b=r 2 a=c a&= 1 a+=b a+=b r=a 2
+      a=c a>>= 1 c=a
+      d-- d--
     else
-      a=c a>>= 1 c=a             (bits>>=1)
-      a=r 2 a<<= 2 b=a           (len<<=2)
-      a=c a&= 3 a+=b r=a 2       (len+=bits&3)
-      a=c a>>= 2 c=a             (bits>>=2)
-      d-- d-- d--                (n-=3)
+      a=c a>>= 1 c=a
+      a=r 2 a<<= 2 b=a
+      a=c a&= 3 a+=b r=a 2
+      a=c a>>= 2 c=a
+      d-- d-- d--
 """
-    p += f"      a= {5 if rb else 2} r=a 1                 (state={5 if rb else 2})\n"
+    p += f"      a= {5 if rb else 2} r=a 1\n"
     p += """    endif
   forever endif endif
-
 """
     if rb:
-        p += f"""  (if state==5 && n>=8) (expect low bits of offset to put in r5)
+        p += f"""
   a=r 1 a== 5 if a=d a> {rb - 1} if
-    a=c a&= {(1 << rb) - 1} r=a 5            (save r in r5)
+    a=c a&= {(1 << rb) - 1} r=a 5
     a=c a>>= {rb} c=a
     a=d a-= {rb} d=a
-    a= 2 r=a 1                   (go to state 2)
+    a= 2 r=a 1
   endif endif
-
 """
-    p += """  (if state==2 && n>=m) (expect m offset bits)
+    p += """
   a=r 1 a== 2 if a=r 3 a>d ifnot
-    a=c r=a 6 a=d r=a 7          (save c=bits, d=n in r6,r7)
-    b=r 3 a= 1 a<<=b d=a         (d=1<<m)
-    a-- a&=c a+=d                (d=offset=bits&((1<<m)-1)|(1<<m))
+    a=c r=a 6 a=d r=a 7
+    b=r 3 a= 1 a<<=b d=a
+    a-- a&=c a+=d
 """
     if rb:
         p += f"    a<<= {rb} d=r 5 a+=d a-= {(1 << rb) - 1}\n"
-    p += """    d=a b=r 4 a=b a-=d c=a       (c=p=(b=ptr)-offset)
+    p += """    d=a b=r 4 a=b a-=d c=a
 
-    (while len-- (copy and output match d bytes from *c to *b))
     d=r 2 do a=d a> 0 if d--
-      a=*c *b=a c++ b++          (buf[ptr++]-buf[p++])
+      a=*c *b=a c++ b++
 """
     if not doe8:
         p += " out\n"
     p += """    forever endif
     a=b r=a 4
 
-    a=r 6 b=r 3 a>>=b c=a        (bits>>=m)
-    a=r 7 a-=b d=a               (n-=m)
-    a=0 r=a 1                    (state=0)
+    a=r 6 b=r 3 a>>=b c=a
+    a=r 7 a-=b d=a
+    a=0 r=a 1
   endif endif
 
-  (while state==3 && n>=2 (expect literal length))
   do a=r 1 a== 3 if a=d a> 1 if
-    a=c a&= 1 a== 1 if         (if bits&1)
-      a=c a>>= 1 c=a              (bits>>=1)
-      b=r 2 a&= 1 a+=b a+=b r=a 2 (len+=len+(bits&1))
-      a=c a>>= 1 c=a              (bits>>=1)
-      d-- d--                     (n-=2)
+    a=c a&= 1 a== 1 if
+      a=c a>>= 1 c=a
+      b=r 2 a&= 1 a+=b a+=b r=a 2
+      a=c a>>= 1 c=a
+      d-- d--
     else
-      a=c a>>= 1 c=a              (bits>>=1)
-      d--                         (--n)
-      a= 4 r=a 1                  (state=4)
+      a=c a>>= 1 c=a
+      d--
+      a= 4 r=a 1
     endif
   forever endif endif
 
-  (if state==4 && n>=8 (expect len literals))
   a=r 1 a== 4 if a=d a> 7 if
     b=r 4 a=c *b=a
 """
     if not doe8:
         p += " out\n"
-    p += """    b++ a=b r=a 4                 (buf[ptr++]=bits)
-    a=c a>>= 8 c=a                (bits>>=8)
-    a=d a-= 8 d=a                 (n-=8)
-    a=r 2 a-- r=a 2 a== 0 if      (if --len<1)
-      a=0 r=a 1                     (state=0)
+    p += """    b++ a=b r=a 4
+    a=c a>>= 8 c=a
+    a=d a-= 8 d=a
+    a=r 2 a-- r=a 2 a== 0 if
+      a=0 r=a 1
     endif
   endif endif
   halt
@@ -206,44 +191,42 @@ end
 def _pcomp_lzpre(args: List[int], doe8: bool) -> str:
     """LibZPAQ.cs:575-639."""
     p = """pcomp lzpre c ;
-  (Decode LZ77: d=state, M=output buffer, b=size)
-  a> 255 if (at EOF decode e8e9 and output)
+
+  a> 255 if
 """
     if doe8:
         p += _E8E9_TAIL
-    p += f"""    b=0 c=0 d=0 a=0 r=a 1 r=a 2 (reset state)
+    p += f"""    b=0 c=0 d=0 a=0 r=a 1 r=a 2
   halt
   endif
 
-  (in state d==0, expect a new code)
-  (put length in r1 and inital part of offset in r2)
   c=a a=d a== 0 if
     a=c a>>= 6 a++ d=a
-    a== 1 if (literal?)
+    a== 1 if
       a+=c r=a 1 a=0 r=a 2
-    else (3 to 5 byte match)
+    else
       d++ a=c a&= 63 a+= {args[2]} r=a 1 a=0 r=a 2
     endif
   else
-    a== 1 if (writing literal)
+    a== 1 if
       a=c *b=a b++
 """
     if not doe8:
         p += " out\n"
-    p += """      a=r 1 a-- a== 0 if d=0 endif r=a 1 (if (--len==0) state=0)
+    p += """      a=r 1 a-- a== 0 if d=0 endif r=a 1
     else
-      a> 2 if (reading offset)
-        a=r 2 a<<= 8 a|=c r=a 2 d-- (off=off<<8|c, --state)
-      else (state==2, write match)
-        a=r 2 a<<= 8 a|=c c=a a=b a-=c a-- c=a (c=i-off-1)
-        d=r 1 (d=len)
-        do (copy and output d=len bytes)
+      a> 2 if
+        a=r 2 a<<= 8 a|=c r=a 2 d--
+      else
+        a=r 2 a<<= 8 a|=c c=a a=b a-=c a-- c=a
+        d=r 1
+        do
           a=*c *b=a c++ b++
 """
     if not doe8:
         p += " out\n"
     p += """        d-- a=d a> 0 while
-        (d=state=0. off, len don't matter)
+
       endif
     endif
   endif
@@ -257,59 +240,49 @@ def _pcomp_bwtrle(args: List[int], doe8: bool) -> str:
     """LibZPAQ.cs:642-795."""
     p = """pcomp bwtrle c ;
 
-  (read BWT, index into M, size in b)
   a> 255 ifnot
     *b=a b++
 
-  (inverse BWT)
   elsel
 
-    (index in last 4 bytes, put in c and R1)
     b-- a=*b
     b-- a<<= 8 a+=*b
     b-- a<<= 8 a+=*b
     b-- a<<= 8 a+=*b c=a r=a 1
 
-    (save size in R2)
     a=b r=a 2
 
-    (count bytes in H[~1..~255, ~0])
     do
       a=b a> 0 if
         b-- a=*b a++ a&= 255 d=a d! *d++
       forever
     endif
 
-    (cumulative counts: H[~i=0..255] = count of bytes before i)
     d=0 d! *d= 1 a=0
     do
       a+=*d *d=a d--
     d<>a a! a> 255 a! d<>a until
 
-    (build first part of linked list in H[0..idx-1])
     b=0 do
       a=c a>b if
         d=*b d! *d++ d=*d d-- *d=b
       b++ forever
     endif
 
-    (rest of list in H[idx+1..n-1])
     b=c b++ c=r 2 do
       a=c a>b if
         d=*b d! *d++ d=*d d-- *d=b
       b++ forever
     endif
-
 """
     if args[0] <= 4:
-        p += """    (copy M to low 8 bits of H to reduce cache misses in next loop)
+        p += """
     b=0 do
       a=c a>b if
         d=b a=*d a<<= 8 a+=*b *d=a
       b++ forever
     endif
 
-    (traverse list and output or copy to M)
     d=r 1 b=0 do
       a=d a== 0 ifnot
         a=*d a>>= 8 d=a
@@ -317,31 +290,24 @@ def _pcomp_bwtrle(args: List[int], doe8: bool) -> str:
         p += " *b=*d b++\n" if doe8 else " a=*d out\n"
         p += """      forever
     endif
-
 """
         if doe8:
-            p += "    (e8e9 transform to out)\n" + _E8E9_TAIL
+            p += "\n" + _E8E9_TAIL
         p += """  endif
   halt
 end
 """
     elif doe8:
-        p += """    (R2 = output size without EOS)
+        p += """
     a=r 2 a-- r=a 2
 
-    (traverse list (d = IBWT pointer) and output inverse e8e9)
-    (C = offset = 0..R2-1)
-    (R4 = last 4 bytes shifted in from MSB end)
-    (R5 = temp pending output byte)
     c=0 d=r 1 do
       a=d a== 0 ifnot
         d=*d
 
-        (store byte in R4 and shift out to R5)
         b=d a=*b a<<= 24 b=a
         a=r 4 r=a 5 a>>= 8 a|=b r=a 4
 
-        (if E8|E9 xx xx xx 00|FF in R4:R5 then subtract c from x)
         a=c a> 3 if
           a=r 5 a&= 254 a== 232 if
             a=r 4 a>>= 24 b=a a++ a&= 254 a< 2 if
@@ -351,13 +317,11 @@ end
           endif
         endif
 
-        (output buffered byte)
         a=c a> 3 if a=r 5 out endif c++
 
       forever
     endif
 
-    (output up to 4 pending bytes in R4)
     b=r 4
     a=c a> 3 a=b if out endif a>>= 8 b=a
     a=c a> 2 a=b if out endif a>>= 8 b=a
@@ -369,7 +333,7 @@ end
 end
 """
     else:
-        p += """    (traverse list and output)
+        p += """
     d=r 1 do
       a=d a== 0 ifnot
         d=*d
@@ -385,7 +349,7 @@ end
 
 def make_config(method: str) -> Tuple[str, List[int]]:
     """Config text (with the $-arguments already substituted) and the nine numeric arguments of a method string."""
-    from .models import E8E9_PCOMP
+    from zpaqsharp_amd.models import E8E9_PCOMP
     typ, args, rest = parse_args(method)
     if typ == "0":
         return "comp 0 0 0 0 0 hcomp end\n", args
@@ -406,16 +370,16 @@ def make_config(method: str) -> Tuple[str, List[int]]:
     comp: List[str] = []
     hc: List[str] = ["hcomp", "c-- *c=a a+= 255 d=a *d=c"]
     if level == 2:
-        hc.append(f"""  a=r 1 a== 0 if (init)
-    a= {111 + 57 * int(doe8)} (skip post code)
-  else a== 1 if  (new code?)
-    a=*c r=a 2  (save code in R2)
-    a> 63 if a>>= 6 a++ a++  (match)
-    else a++ a++ endif  (literal)
-  else (read rest of code)
+        hc.append(f"""  a=r 1 a== 0 if
+    a= {111 + 57 * int(doe8)}
+  else a== 1 if
+    a=*c r=a 2
+    a> 63 if a>>= 6 a++ a++
+    else a++ a++ endif
+  else
     a--
   endif endif
-  r=a 1  (R1 = 1+expected bytes to next code)""")
+  r=a 1""")
     for m in re.finditer(r"([a-z])([0-9,.]*)", rest):
         if ncomp >= 254:
             break
@@ -709,7 +673,7 @@ def compress_block(method: str, data: bytes, filename: bytes = b"", pre: bytes =
     encoder writes; the size comment and SHA-1 still describe `data`)."""
     import hashlib
 
-    from . import synth
+    from zpaqsharp_amd import synth
     model, args = model_of(method)
     if pre is None:
         pre = preprocess(data, args)

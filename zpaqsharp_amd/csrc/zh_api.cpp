@@ -56,6 +56,9 @@ struct zpaqhip_ctx {
   // buffers, pinned chunks for the Writer callback
   hipStream_t s_in = nullptr, s_out = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_pin[2] = {nullptr, nullptr}, ev_h0 = nullptr, ev_h1 = nullptr;
+  hipEvent_t ev_d[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // D2H of a batch slot: first copy enqueued / last copy done
+  bool d_pending[2] = {false, false};
+  float d2h_acc = 0;
   DevBuf in2[2], out2[2], out_fix[2];
   uint8_t *pin[2] = {nullptr, nullptr};
   zpaqhip_stats stats{};
@@ -141,6 +144,7 @@ void zpaqhip_ctx_destroy(zpaqhip_ctx *c) {
     if (c->pin[i]) (void)hipHostFree(c->pin[i]);
     if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
     if (c->ev_pin[i]) (void)hipEventDestroy(c->ev_pin[i]);
+    for (int k = 0; k < 2; ++k) if (c->ev_d[i][k]) (void)hipEventDestroy(c->ev_d[i][k]);
   }
   if (c->ev_h0) (void)hipEventDestroy(c->ev_h0);
   if (c->ev_h1) (void)hipEventDestroy(c->ev_h1);
@@ -212,6 +216,12 @@ struct zh_pending {
   uint64_t total_in = 0, total_model = 0;
   uint32_t launches = 0, slots = 0, kind_used = 0;
   bool prof = false, active = false;
+  // sources of the launch's asynchronous H2D copies: they must outlive decode_launch (the API does not promise that a
+  // pageable hipMemcpyAsync has read its source when it returns)
+  std::vector<ZhModel> models;
+  std::vector<uint8_t> code;
+  std::vector<ZhSegDesc> sd;
+  std::vector<ZhBlockDesc> bd_sorted;
 };
 
 static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, size_t in_len,
@@ -234,10 +244,11 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
 
   // ---- models: one per distinct header
   std::map<std::string, uint32_t> model_of;
-  std::vector<ZhModel> models;
-  std::vector<uint8_t> code;
+  std::vector<ZhModel> &models = P.models;
+  std::vector<uint8_t> &code = P.code;
   std::vector<ZhBlockDesc> bd(sel.size());
-  std::vector<ZhSegDesc> sd(n_segs);
+  std::vector<ZhSegDesc> &sd = P.sd;
+  sd.assign(n_segs, ZhSegDesc{});
   std::vector<uint8_t> hdr;
   uint64_t total_in = 0, total_model = 0;
   for (size_t k = 0; k < sel.size(); ++k) {
@@ -324,7 +335,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
   }
   HIPCHK(c->arena.reserve((size_t)arena_need));
 
-  std::vector<ZhBlockDesc> bd_sorted;
+  std::vector<ZhBlockDesc> &bd_sorted = P.bd_sorted;
   bd_sorted.reserve(sel.size());
   size_t base_of[ZH_NFAM] = {};
   for (uint32_t g = 0; g < ZH_NFAM; ++g) {
@@ -524,6 +535,36 @@ struct Sinkk {
 constexpr size_t kBatchMinBlocks = 256, kBatchMinBytes = 32u << 20, kBatchMaxBlocks = 4096;
 constexpr size_t kReadChunk = 4u << 20, kPinChunk = 32u << 20;
 
+// A header the framing scan accepts can still be refused when the model is built (component limits, table sizes:
+// Predictor.cs:94-167).  The reference raises that at the block's Predictor.init, after everything before the block has
+// been written; so the batch is cut in front of the first such block and the error is reported behind the cut.
+void cut_at_bad_model(Batch &bt) {
+  std::map<std::string, int> seen;
+  for (size_t b = 0; b < bt.so.blocks.size(); ++b) {
+    const zpaqhip_block &B = bt.so.blocks[b];
+    std::string key((const char *)bt.h + B.hdr_off, B.hdr_len);
+    auto it = seen.find(key);
+    zpaqhip_err e2{};
+    if (it == seen.end()) {
+      ZhModel m;
+      std::vector<uint8_t> code;
+      it = seen.emplace(key, build_model(bt.h + B.hdr_off, B.hdr_len, m, code, &e2)).first;
+    } else if (it->second) {
+      ZhModel m;
+      std::vector<uint8_t> code;
+      (void)build_model(bt.h + B.hdr_off, B.hdr_len, m, code, &e2);     // (again, for the message)
+    }
+    if (!it->second) continue;
+    e2.block = (int32_t)b; e2.segment = -1;
+    bt.rc_after = it->second; bt.err_after = e2; bt.last = true;
+    bt.so.blocks.resize(b);
+    bt.so.segs.resize(b ? bt.so.blocks.back().first_seg + bt.so.blocks.back().n_seg : 0);
+    bt.so.stopped = false;
+    bt.len = b ? (size_t)bt.so.blocks.back().end_off : 0;
+    return;
+  }
+}
+
 // Next batch of whole blocks, or batch.so.blocks.empty() at the end of the stream.  Returns a call-level error only.
 int next_batch(Source &src, Batch &bt, size_t blk0, size_t seg0, size_t batch_blocks, zpaqhip_err *err) {
   ScanLimit lim;
@@ -541,6 +582,8 @@ int next_batch(Source &src, Batch &bt, size_t blk0, size_t seg0, size_t batch_bl
     if (rc) { bt.rc_after = rc; bt.err_after = e2; bt.last = true; src.mem_pos = src.mem_len; }
     else if (bt.so.stopped) src.mem_pos += bt.so.resume_off;
     else { bt.last = true; src.mem_pos = src.mem_len; }
+    cut_at_bad_model(bt);
+    if (bt.last) src.mem_pos = src.mem_len;
     return ZPAQHIP_OK;
   }
   for (;;) {                                            // Reader form: read until a batch is complete or the input ends
@@ -568,6 +611,7 @@ int next_batch(Source &src, Batch &bt, size_t blk0, size_t seg0, size_t batch_bl
     src.buf.erase(src.buf.begin(), src.buf.begin() + (ptrdiff_t)keep_from);
     src.consumed += keep_from;
     bt.h = bt.own.data();
+    cut_at_bad_model(bt);
     return ZPAQHIP_OK;
   }
 }
@@ -699,8 +743,25 @@ const uint8_t *block_dev_ptr(zpaqhip_ctx *c, const Batch &bt, size_t b) {
 }
 
 // Deliver the first `upto_blocks` blocks (plus `partial` bytes of the next one) of a decoded batch to the sink, in order.
+// D2H time of a batch slot's last drain (memory and placed forms), added to c->d2h_acc once the copies are done
+int harvest_d2h(zpaqhip_ctx *c, int slot, zpaqhip_err *err) {
+  if (!c->d_pending[slot]) return ZPAQHIP_OK;
+  c->d_pending[slot] = false;
+  HIPCHK(hipEventSynchronize(c->ev_d[slot][1]));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev_d[slot][0], c->ev_d[slot][1]));
+  c->d2h_acc += ms;
+  return ZPAQHIP_OK;
+}
+
 int drain_batch(zpaqhip_ctx *c, const Batch &bt, size_t upto_blocks, uint64_t partial, Sinkk &sink, zpaqhip_err *err) {
   struct Piece { const uint8_t *p; uint64_t n; };
+  const bool timed = sink.place || sink.mem || !sink.wr;
+  if (timed) {
+    int hrc = harvest_d2h(c, bt.slot, err);
+    if (hrc) return hrc;
+    HIPCHK(hipEventRecord(c->ev_d[bt.slot][0], c->s_out));
+  }
   std::vector<Piece> pieces;
   for (size_t b = 0; b <= upto_blocks && b < bt.so.blocks.size(); ++b) {
     const uint64_t n = b < upto_blocks ? bt.real[b] : std::min<uint64_t>(partial, bt.real[b]);
@@ -717,6 +778,8 @@ int drain_batch(zpaqhip_ctx *c, const Batch &bt, size_t upto_blocks, uint64_t pa
         HIPCHK(hipMemcpyAsync(sink.mem + at, block_dev_ptr(c, bt, b), (size_t)std::min<uint64_t>(n, sink.cap - at), hipMemcpyDeviceToHost, c->s_out));
       sink.total += n;
     }
+    HIPCHK(hipEventRecord(c->ev_d[bt.slot][1], c->s_out));
+    c->d_pending[bt.slot] = true;
     return ZPAQHIP_OK;
   }
   if (sink.mem || !sink.wr) {
@@ -727,6 +790,8 @@ int drain_batch(zpaqhip_ctx *c, const Batch &bt, size_t upto_blocks, uint64_t pa
       }
       sink.total += pc.n;
     }
+    HIPCHK(hipEventRecord(c->ev_d[bt.slot][1], c->s_out));
+    c->d_pending[bt.slot] = true;
     return ZPAQHIP_OK;
   }
   // Writer form: pinned double buffer; the copy of chunk i+1 runs while write_fn consumes chunk i
@@ -775,16 +840,22 @@ struct SegSink {                          // zpaqhip_decompress_segments: per-se
 };
 
 // The pipeline.  `tolerate`: per-segment data errors do not end the call (zpaqhip_decompress_segments).
+// *stream_error: the returned code describes the stream (damage behind the delivered blocks), not a failure of the call.
 int run_pipeline(zpaqhip_ctx *c, Source &src, Sinkk &sink, const zpaqhip_opts &opts, bool tolerate, SegSink *segsink,
-                 zpaqhip_err *err) {
+                 zpaqhip_err *err, bool *stream_error = nullptr) {
+  if (stream_error) *stream_error = false;
   HIPCHK(hipSetDevice(c->device));
   if (!c->s_in) {
     HIPCHK(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreate(&c->ev_in[i])); HIPCHK(hipEventCreate(&c->ev_pin[i])); }
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(hipEventCreate(&c->ev_in[i])); HIPCHK(hipEventCreate(&c->ev_pin[i]));
+      HIPCHK(hipEventCreate(&c->ev_d[i][0])); HIPCHK(hipEventCreate(&c->ev_d[i][1]));
+    }
     HIPCHK(hipEventCreate(&c->ev_h0)); HIPCHK(hipEventCreate(&c->ev_h1));
   }
   zpaqhip_stats acc{};
+  c->d2h_acc = 0; c->d_pending[0] = c->d_pending[1] = false;
   Batch bt[2];
   zh_pending P;
   size_t blk0 = 0, seg0 = 0;
@@ -819,7 +890,11 @@ int run_pipeline(zpaqhip_ctx *c, Source &src, Sinkk &sink, const zpaqhip_opts &o
       HIPCHK(hipStreamWaitEvent(c->stream, c->ev_in[B.slot], 0));
       rc = decode_launch(c, c->in2[B.slot].p, B.h, B.len, B.so.blocks.data(), B.so.blocks.size(), B.so.segs.data(),
                          B.so.segs.size(), nullptr, 0, c->out2[B.slot].p, B.off.data(), B.cap.data(), opts, c->stream, P, err);
-      if (rc) { rebase_err(err, B); return rc; }
+      if (rc) {                                          // (device memory, HIP): what is already decoded is delivered first
+        rebase_err(err, B);
+        if (have_prev) { zpaqhip_err e3{}; (void)drain_batch(c, bt[cur ^ 1], bt[cur ^ 1].so.blocks.size(), 0, sink, &e3); (void)hipStreamSynchronize(c->s_out); }
+        return rc;
+      }
     }
     // ---- while the kernels run: deliver the previous batch, fetch and upload the next one
     Batch &prev = bt[cur ^ 1];
@@ -911,12 +986,13 @@ int run_pipeline(zpaqhip_ctx *c, Source &src, Sinkk &sink, const zpaqhip_opts &o
     cur ^= 1;
   }
   { float ms = 0; if (hipEventElapsedTime(&ms, c->ev_h0, c->ev_h1) == hipSuccess) h2d_ms += ms; else (void)hipGetLastError(); }
-  HIPCHK(hipEventRecord(c->ev_h0, c->s_out));
   HIPCHK(hipStreamSynchronize(c->s_out));
+  for (int i = 0; i < 2; ++i) { int hrc = harvest_d2h(c, i, err); if (hrc) return hrc; }
   c->stats = acc;
   c->stats.h2d_ms = h2d_ms;
+  c->stats.d2h_ms = c->d2h_acc;                          // copy-stream time of the plaintext (memory forms; it overlaps the kernels)
   c->stats.out_bytes = sink.total;
-  if (final_rc) { if (err) *err = final_err; return final_rc; }
+  if (final_rc) { if (err) *err = final_err; if (stream_error) *stream_error = true; return final_rc; }
   return ZPAQHIP_OK;
 }
 
@@ -931,10 +1007,7 @@ int zpaqhip_decompress(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint8_t
   Source src; src.mem = in ? in : (const uint8_t *)""; src.mem_len = in_len;
   Sinkk sink; sink.mem = out; sink.cap = out_cap;
   *out_len = 0;
-  const auto t0 = std::chrono::steady_clock::now();
   int rc = run_pipeline(c, src, sink, opts, false, nullptr, err);
-  c->stats.d2h_ms = 0;
-  (void)t0;
   *out_len = (size_t)sink.total;
   if (rc) return rc;
   if (sink.total > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, -1, -1); return ZPAQHIP_E_OUTPUT_FULL; }
@@ -1080,10 +1153,11 @@ int zpaqhip_decompress_segments(zpaqhip_ctx *c, const uint8_t *in, size_t in_len
   Sinkk sink; sink.mem = out; sink.cap = out_cap;
   SegSink ss;
   *out_len = 0; *n_results = 0;
-  int rc = run_pipeline(c, src, sink, opts, true, &ss, err);
+  bool stream_error = false;
+  int rc = run_pipeline(c, src, sink, opts, true, &ss, err, &stream_error);
   *out_len = (size_t)sink.total;
   *n_results = ss.res.size();
-  if (rc && !data_error(rc)) return rc;
+  if (rc && !stream_error) return rc;                    // the call itself failed (device, arguments, callback)
   const int frame_rc = rc;                               // a framing error after the last good block: reported below
   if (ss.res.size() > result_cap) { set_err(err, ZPAQHIP_E_ARG, -1, -1, "result table too small"); return ZPAQHIP_E_ARG; }
   if (!ss.res.empty()) memcpy(results, ss.res.data(), ss.res.size() * sizeof(zpaqhip_seg_result));

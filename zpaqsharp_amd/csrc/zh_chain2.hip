@@ -272,7 +272,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane) {
     while ((cmd = c2_ld(&S.mb_cmd)) == seen_cmd) { __builtin_amdgcn_s_sleep(4); if (++sp > kC2Spin) return; }
     seen_cmd = cmd;
     if ((cmd & 3u) == kC2Exit) return;
-    if ((cmd & 3u) != kC2New) continue;
+    if ((cmd & 3u) != kC2New) { c2_put0(&S.mb_ack, cmd); continue; }   // End: acknowledged once this wave has left the block (its last commit is in LDS)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const ZhModel *M = &L.models[uni(c2_ld(&S.mb_model))];
     const uint32_t arena_bytes = uni((uint32_t)M->arena_bytes);
@@ -1188,7 +1188,11 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     }
     if (PROF && lane == 0 && L.debug)
       for (int i = 0; i < 12; ++i) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
-    if (HELP) { ++cmd_seq; c2_put0(&S.mb_cmd, cmd_seq << 2 | kC2End); }     // the helper wave waits for the next block
+    if (HELP) {                                         // the helper wave leaves the block; its late commit of the last byte
+      ++cmd_seq;                                        // (S.mreg / S.hreg) must be in LDS before this wave zeroes them again
+      c2_put0(&S.mb_cmd, cmd_seq << 2 | kC2End);
+      (void)c2_wait(&S.mb_ack, cmd_seq << 2 | kC2End);
+    }
     c2_wave_sync();
   }
   if (HELP) { ++cmd_seq; c2_put0(&S.mb_cmd, cmd_seq << 2 | kC2Exit); }
@@ -1196,6 +1200,13 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
 
 }  // namespace
 
+// The two-wave protocol rests on properties of gfx9-family hardware in its default (non-tgsplit) mode: both waves of the
+// workgroup run on one CU and share its vector L1 and its LDS; a wave's vector memory operations complete in issue order
+// (one vmcnt for loads and stores).  LLVM AMDGPU memory model, "Memory Model gfx90a/gfx942": in non-threadgroup-split
+// mode the wavefronts of a work-group share the L1, so workgroup-scope ordering needs no cache maintenance.
+#if !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__) && defined(__HIP_DEVICE_COMPILE__)
+#error "zh_chain2.hip: the helper-wave protocol is written for gfx9-family CUs (shared vector L1, in-order vmcnt)"
+#endif
 #define ZH_CHAIN2_KERNEL(name, spec, prof)                                             \
   extern "C" __global__ __launch_bounds__(spec::helper ? 128 : 64) void name(ZhLaunch L) {  \
     typedef C2LdsT<spec::has_tail, spec::helper> Lds;                                  \

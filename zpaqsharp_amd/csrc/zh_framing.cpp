@@ -269,7 +269,11 @@ static int scan_blocks(Cur &c, const uint8_t *in, ScanOut &out, zpaqhip_err *err
         int v = 0;
         for (int i = 0; i < 4 && (v = c.get()) >= 0; ++i) curr = curr << 8 | (uint32_t)v;
         while (curr > 0 && v >= 0) {
-          if (c.n - c.pos < curr) { set_err(err, ZPAQHIP_E_EOF, bi, si, "skipped to EOF"); return ZPAQHIP_E_EOF; }
+          if (c.n - c.pos < curr) {                    // the chunk runs past what has been read: more input may repair it
+            c.eof_hit = true;
+            set_err(err, ZPAQHIP_E_EOF, bi, si, "skipped to EOF");
+            return ZPAQHIP_E_EOF;
+          }
           c.pos += curr;
           curr = 0;
           for (int i = 0; i < 4 && (v = c.get()) >= 0; ++i) curr = curr << 8 | (uint32_t)v;
