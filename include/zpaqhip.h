@@ -117,7 +117,9 @@ typedef struct zpaqhip_opts {
   uint32_t max_concurrent;    /* blocks in flight per launch; 0 = auto (memory-bound) */
   uint32_t kernel;            /* 0 auto; 1 force the generic (one-lane) kernel; 3 prefer the lane-per-component kernel;
                                  4 lane-per-component without model specialisation; 5 the run-time-level form of the
-                                 lane-per-component kernel also for the built-in min/mid/max models (cross-check) */
+                                 lane-per-component kernel also for the built-in min/mid/max models (cross-check);
+                                 8 the three-wave form (decoder wave, speculating model wave, helper wave) for the built-in
+                                 mid/max models, 7 the same without speculation (experimental: bit-exact, not faster yet) */
   uint64_t zpaql_budget;      /* runaway-program guard, per run() call: max ZPAQL instructions on the interpreter, max backward
                                  jumps in an ahead-of-time translated program (a translation checks where it can loop);
                                  0 = default (1<<32).  Exceeding it ends the block with ZPAQHIP_E_BUDGET */

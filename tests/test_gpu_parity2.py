@@ -265,6 +265,50 @@ def test_chain_models_on_repetitive_plaintext(ctx, model):
     assert len(got) == len(want)
 
 
+@pytest.mark.parametrize("kernel", [8, 7])
+@pytest.mark.parametrize("model", ["mid", "max", "max+e8e9"])
+def test_three_wave_kernels_match_the_oracle(ctx, model, kernel):
+    """zh_chain3.hip (opt-in: decoder wave ‖ speculating model wave ‖ helper wave; kernel 7 = without speculation) on the
+    repetitive plaintexts that collide hash rows and repeat mixer contexts, several segments per block, an empty block
+    and a block of 600 KB; every result against the oracle and the two-wave kernel."""
+    blocks, plains = [], []
+    for name, d in _repetitive_plaintexts():
+        plains.append(d.tobytes())
+        blocks.append(synth.compress_block(model, d))
+    big = util.text(600_000, seed=31) if "e8e9" not in model else util.x86ish(600_000, seed=31)
+    for d in (b"", b"a", b"aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa" * 50, big):
+        plains.append(d)
+        blocks.append(util.block(model, d))
+    s = b"".join(blocks)
+    want = b"".join(plains)
+    got = ctx.decompress(s, verify_sha1="e8e9" not in model, kernel=kernel).tobytes()
+    assert got == want
+    assert ctx.decompress(s, kernel=0).tobytes() == want
+    if "e8e9" not in model:                                  # several segments in one block: the model carries over
+        a, b, c = util.text(5000, 1), util.text(3000, 2), b""
+        m = models.get(model)
+        comp = oracle.Compressor(40000)
+        comp.write_tag(); comp.start_block(m.header)
+        for i, seg in enumerate((a, b, c)):
+            comp.start_segment(b"f", str(len(seg)).encode())
+            if i == 0:
+                comp.post_process(m.pcomp)
+            comp.compress(seg)
+            comp.end_segment(oracle.sha1(seg))
+        comp.end_block()
+        ms = comp.getvalue(); comp.close()
+        assert oracle.decompress(ms) == a + b + c
+        assert ctx.decompress(ms, verify_sha1=True, kernel=kernel).tobytes() == a + b + c
+    # a damaged stream ends with the oracle's error, not with a hang of a partner wave
+    bad = bytearray(util.block(model, util.text(20000, seed=9)))
+    bad[z.scan(bytes(bad)).segments[0].data_off + 300] ^= 0x10
+    with pytest.raises(z.ZpaqError) as e1:
+        ctx.decompress(bytes(bad), kernel=kernel)
+    with pytest.raises(z.ZpaqError) as e0:
+        ctx.decompress(bytes(bad), kernel=0)
+    assert e1.value.code == e0.value.code
+
+
 def test_two_ranks_on_one_gpu_run_the_sharded_hip_decode(tmp_path):
     """bench.py's N > 1 path — shared stream, broadcast table, LPT plan, zpaqhip_decode_blocks_device(ids = shard),
     all_gather of the results — rehearsed with two gloo ranks that share this box's one GPU."""

@@ -6,7 +6,7 @@ import zpaqsharp_amd as z
 from tests import util
 model = sys.argv[1] if len(sys.argv) > 1 else "mid"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
-kern = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+kern = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 data = util.text(n, seed=5)
 s = util.block(model, data)
 sc = z.scan(s)

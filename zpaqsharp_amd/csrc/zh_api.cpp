@@ -373,7 +373,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     if (prof) L.debug = (uint64_t *)((uint8_t *)c->queue.p + kQueueBytes);
     if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, slots_of[g], stream));
     else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, slots_of[g], stream));
-    else if (g > ZH_FAM_CHAIN && zh_chain3_has(g - ZH_FAM_CHAIN) && opts.kernel != 5 && opts.kernel != 6)   // decoder ‖ model ‖ helper wave (zh_chain3.hip)
+    else if (g > ZH_FAM_CHAIN && zh_chain3_has(g - ZH_FAM_CHAIN) && (opts.kernel == 7 || opts.kernel == 8))   // decoder ‖ model ‖ helper wave (zh_chain3.hip): opt-in
       HIPCHK(zh_launch_chain3(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof ? 2 : opts.kernel == 7));
     else if (g > ZH_FAM_CHAIN && zh_chain2_has(g - ZH_FAM_CHAIN) && opts.kernel != 5)   // per-model bit loop (zh_chain2.hip)
       HIPCHK(zh_launch_chain2(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));

@@ -62,8 +62,9 @@ constexpr int kHWords = 256, kMBytes = 4096, kCodeBytes = 2048, kPHWords = 256, 
 constexpr int kEntUnits = 15;                 // ICM / ISSE entry tables of 256 x 8 bytes
 
 constexpr int kSpecUnits = 8, kSpecH = 8, kSpecHMax = 32;      // helper wave staging: ICM/ISSE components and H words per candidate (min / mid)
-template <bool TAIL, int HELP>
+template <bool TAIL, int HELP, bool MIXLDS = false>
 struct alignas(16) C2LdsT {
+  static constexpr bool kMixLds = MIXLDS;
   int16_t stretch[32768];                     // at LDS offset 0 of this struct: see lds_stretch()
   uint16_t squash[4096];
   int32_t dt[1024];
@@ -86,7 +87,13 @@ struct alignas(16) C2LdsT {
   uint32_t mb_ack2, mb_block;                 // the model wave's acknowledgement; block index of the command
   uint32_t yv;                                // decoder -> model: bit sequence number << 8 | the last 8 decoded bits
   uint32_t pv[2][2][16];                      // model -> decoder: [seq & 1][hypothesis for the bit before][component] = seq << 12 | p & 0xfff
-  v4u_ xfer[64];                              // model wave: state of the winning hypothesis -> all lanes
+  v4u_ xfer[128];                             // model wave: state of the winning hypothesis -> all lanes ([lane], [64 + lane])
+  // MIXLDS (zh_chain3.hip, mid): the mixer's weights come to the decoder wave through LDS, brought by the helper wave.
+  // A byte's 255 rows are one block of 256 x m weights (row = context + c8); mixblk holds the block of the byte being
+  // decoded (and, in its other half, the one before); mixrow8 holds rows 0-7 of the block each candidate byte leads to
+  uint32_t mixrow8[MIXLDS ? 16 : 1][64];
+  uint32_t mixblk[MIXLDS ? 2 : 1][MIXLDS ? 1792 : 1];
+  uint32_t mb_blk;                            // helper -> decoder: byte sequence number << 1 | half of mixblk the next byte's block is in
   uint32_t hreg[kHWords];
   uint8_t mreg[kMBytes];
   uint32_t r[256], pr[256];
@@ -96,7 +103,7 @@ struct alignas(16) C2LdsT {
   Vm hz, pz;
   Sink sink;
 };
-static_assert(sizeof(C2LdsT<true, 2>) <= 163840 && sizeof(C2LdsT<false, 1>) <= 163840, "LDS budget");
+static_assert(sizeof(C2LdsT<true, 2>) <= 163840 && sizeof(C2LdsT<false, 1>) <= 163840 && sizeof(C2LdsT<false, 1, true>) <= 163840, "LDS budget");
 
 typedef __attribute__((address_space(3))) uint8_t *lds_u8_p;
 typedef __attribute__((address_space(3))) uint16_t *lds_u16_p;
@@ -280,6 +287,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       const ZhComp &mc = M->comp[SP::mix_lane[q]];
       mx_base[q] = uni((uint32_t)mc.cm_off); mx_size1[q] = uni(mc.cm_mask);
     }
+    uint32_t mix_blk = 0, mix_par = 0;                    // MIXLDS: block in S.mixblk[mix_par] (block 0 at the start: the decoder wave fills it)
     uint32_t hb = 0, hc = 0, hd = 0, hf = 0;              // committed HCOMP registers (A is the input at every run; M and H: S.mreg / S.hreg, zeroed by A)
     c2_put0(&S.mb_ack, cmd);
     uint32_t seq = 1;
@@ -324,8 +332,17 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       }
       // ---- mixer rows for c8 = 1: weights grp, grp+4, grp+8, grp+12 of the row of candidate `cand`
       uint32_t mwv[2][4];
+      v4u mrow8[4];
+      if constexpr (LDS::kMixLds) {             // rows 0-7 of the candidate's block: 8 x m x 4 <= 256 bytes, 16 chunks of 16
+        uint32_t hq = 0;
 #pragma unroll
-      for (uint32_t q = 0; q < SP::nmix; ++q) {
+        for (uint32_t d = 0; d < NH; ++d) if ((SP::mix_lane[0] & (NH - 1u)) == d) hq = (uint32_t)sh[d];
+        const uint32_t b0 = mx_base[0] + (hq & mx_size1[0] & ~255u) * (SP::mix_m[0] * 4u);
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) mrow8[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, b0 + (grp + 4u * t) * 16u, 0, 0);
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < (LDS::kMixLds ? 0u : SP::nmix); ++q) {
         uint32_t hq = 0;
 #pragma unroll
         for (uint32_t d = 0; d < NH; ++d) if ((SP::mix_lane[q] & (NH - 1u)) == d) hq = (uint32_t)sh[d];
@@ -345,9 +362,13 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
         }
       }
 #pragma unroll
-      for (uint32_t q = 0; q < SP::nmix; ++q)
+      for (uint32_t q = 0; q < (LDS::kMixLds ? 0u : SP::nmix); ++q)
 #pragma unroll
         for (uint32_t t = 0; t < 4; ++t) S.mixst[q][cand][grp + 4u * t] = mwv[q][t];
+      if constexpr (LDS::kMixLds) {
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) *(lds_u4_p)lds_off(&S.mixrow8[cand][(grp + 4u * t) * 4u]) = mrow8[t];
+      }
       }
       asm volatile("" ::: "memory");
       c2_put0(&S.mb_ready, seq);
@@ -385,6 +406,22 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       const uint32_t cwi = rdlane(wi, lo), cwv = rdlane(wv, lo), cwn = rdlane(wn, lo);
       if (cwn && lane == 0) S.mreg[cwi] = (uint8_t)cwv;
       if (lane < NH) { const uint32_t hv_ = S.hspec[lane][lo]; S.hreg[lane] = hv_; }
+      if constexpr (LDS::kMixLds) {
+        // the block of mixer rows the NEXT byte uses (its context is known now) -> the other half of mixblk; a byte
+        // that keeps the context keeps the block, which the decoder wave has kept up to date
+        const uint32_t blk = S.hspec[SP::mix_lane[0] & (NH - 1u)][lo] & mx_size1[0] & ~255u;
+        if (blk != mix_blk) {
+          mix_blk = blk; mix_par ^= 1u;
+          const uint32_t b0 = mx_base[0] + blk * (SP::mix_m[0] * 4u);
+          v4u chunk[7];
+#pragma unroll
+          for (uint32_t t = 0; t < 7; ++t) chunk[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, b0 + (lane + 64u * t) * 16u, 0, 0);
+#pragma unroll
+          for (uint32_t t = 0; t < 7; ++t) *(lds_u4_p)lds_off(&S.mixblk[mix_par][(lane + 64u * t) * 4u]) = chunk[t];
+        }
+        asm volatile("" ::: "memory");
+        c2_put0(&S.mb_blk, seq << 1 | mix_par);
+      }
       ++seq;
     }
   }

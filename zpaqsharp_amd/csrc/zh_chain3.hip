@@ -256,16 +256,31 @@ __device__ void c3_model(const ZhLaunch &L, LDS &S, uint32_t lane) {
     };
     // the bit with sequence number sq, as soon as the decoder wave has published it
     auto wait_bit = [&](uint32_t sq, int slot) __attribute__((always_inline)) -> uint32_t {
-      uint32_t v, d, spin = 0;
+      const uint32_t addr = lds_off(&S.yv);
+      uint32_t v = 0, d = 0, tmp, rounds = 0;
       uint64_t t0 = 0;
       if (PROF) t0 = now();
       for (;;) {
-        v = c2_ld(&S.yv);
-        d = ((v >> 8) - sq) & 0xFFFFFFu;                  // 24-bit sequence numbers
-        if (d <= 1u) break;                              // (the decoder wave is at most one bit ahead)
-        if ((++spin & 63u) == 0 && (c2_ld(&S.mb_cmd) != seen_cmd || spin > kC3Spin)) {
-          alive = false; return 0u;
-        }
+        uint32_t left = 1u << 14;
+        asm volatile(
+            ".Lwb_%=:\n\t"
+            "ds_read_b32 %[t], %[a]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_readfirstlane_b32 %[v], %[t]\n\t"
+            "s_lshr_b32 %[d], %[v], 8\n\t"
+            "s_sub_u32 %[d], %[d], %[q]\n\t"
+            "s_and_b32 %[d], %[d], 0xffffff\n\t"
+            "s_cmp_lt_u32 %[d], 2\n\t"                   // (the decoder wave is at most one bit ahead)
+            "s_cbranch_scc1 .Lwd_%=\n\t"
+            "s_sub_u32 %[l], %[l], 1\n\t"
+            "s_cmp_lg_u32 %[l], 0\n\t"
+            "s_cbranch_scc1 .Lwb_%=\n"
+            ".Lwd_%=:"
+            : [t] "=&v"(tmp), [v] "=&s"(v), [d] "=&s"(d), [l] "+s"(left)
+            : [a] "v"(addr), [q] "s"(sq)
+            : "memory", "scc");
+        if (LIKELY(left != 0)) break;
+        if (c2_ld(&S.mb_cmd) != seen_cmd || ++rounds > (1u << 10)) { alive = false; return 0u; }   // the block was given up
       }
       if (PROF) mprof[slot] += now() - t0;
       return (v >> d) & 1u;
@@ -292,7 +307,7 @@ __device__ void c3_model(const ZhLaunch &L, LDS &S, uint32_t lane) {
         hm = uni(hm); c8 = uni(c8);
         if (SP::match_lane >= 0 && bit == 4) match_prefetch();
         uint32_t y = 0;
-        if (!spec_step) { y = wait_bit(bs, bit == 3 ? 1 : 2); if (!alive) break; }
+        if (!spec_step) { y = wait_bit(bs, bit == 3 ? 1 : 2); if (UNLIKELY(!alive)) break; }
         const uint32_t yh = spec_step ? g : y;            // the bit this lane works with
         // ---- Predictor.update for bit `bs` under yh (Predictor.cs:363-461)
         const int ey = yh ? 32767 : 0;
@@ -324,7 +339,7 @@ __device__ void c3_model(const ZhLaunch &L, LDS &S, uint32_t lane) {
           *(lds_u4_p)xf_own = v4u{eA, eB, (uint32_t)sqp, st};
           pm0 = opm0; pm1 = opm1;
           y = wait_bit(bs, 0);
-          if (!alive) break;
+          if (UNLIKELY(!alive)) break;
           if (g == y) {                                   // the half that was right commits its writes
             *(lds_u2_p)oea = v2u{nA, nB};
             *(lds_u8_p)(wrow + (ohm & wrow_mask)) = (uint8_t)nsb;
@@ -474,14 +489,16 @@ __device__ void c3_decoder(const ZhLaunch &L, LDS &S, uint32_t lane) {
     helper_ok = helper_ok && model_ok;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
-    // Mixers kept in HBM (Predictor.cs:302-316, 427-439).  This wave's loop per bit is short, so a weight row requested
-    // when its bit begins would arrive hundreds of cycles late: rows are requested THREE BITS AHEAD, for all 8 values
-    // those bits can take.  The 8 candidate rows of a bit are consecutive (row = base + c8 * m: zh_chain2.hip), so they
-    // come with two loads: lane = 16 rr + l holds weight l of candidate row rr (+4 in the second register).  The
-    // predictions are replicated in the four DPP rows, all candidates' dot products are formed at once and the sum of the
-    // row that came true is read from its last lane.
-    const uint32_t rr = lane >> 4, lw = lane & 15u;
-    uint32_t vo_w4[2] = {kOob, kOob}, vo_w2[2] = {kOob, kOob}, vo_w1[2] = {kOob, kOob}, vo_l[2] = {kOob, kOob};
+    // Mixers (Predictor.cs:302-316, 427-439): lane k owns weight k of the current row.
+    //  * max: rows in HBM, the two rows the next bit can lead to requested while this bit is decoded (zh_chain2.hip); this
+    //    wave's step is long enough for that.
+    //  * mid (MIXLDS): the step is short, a row requested when its bit begins would arrive hundreds of cycles late, and
+    //    waiting on vmcnt behind the training stores is worse still.  The helper wave brings the byte's whole block of rows
+    //    into LDS (zh_c2_common.h); this wave reads weights from there, trains them there and writes the trained row to
+    //    HBM without ever waiting for memory.
+    constexpr bool MIXLDS = LDS::kMixLds;
+    static_assert(!MIXLDS || (SP::nmix == 1 && SP::mix_j0[0] == 0 && SP::mix_m[0] == 7), "MIXLDS is laid out for the mid model's mixer");
+    uint32_t vo_mix[2] = {kOob, kOob};
     uint32_t mx_base[2] = {0, 0}, mx_m4[2] = {0, 0}, mx_size1[2] = {0, 0};
     int mx_rate[2] = {0, 0};
 #pragma unroll
@@ -491,14 +508,9 @@ __device__ void c3_decoder(const ZhLaunch &L, LDS &S, uint32_t lane) {
       mx_m4[q] = SP::mix_m[q] * 4u;
       mx_size1[q] = uni(mc.cm_mask);
       mx_rate[q] = (int)uni((uint32_t)mc.arg[3]);
-      static_assert(SP::mix_j0[0] == 0 && SP::mix_j0[1] == 0 && SP::mix_m[0] <= 16 && SP::mix_m[1] <= 16, "mixer inputs are components 0..m-1, one DPP row");
-      if (lw < SP::mix_m[q]) {
-        vo_l[q] = lw * 4u;
-        vo_w4[q] = rr * mx_m4[q] + lw * 4u;
-        if (rr < 2) vo_w2[q] = vo_w4[q];
-        if (rr < 1) vo_w1[q] = vo_w4[q];
-      }
+      if (lane >= SP::mix_j0[q] && lane < SP::mix_j0[q] + SP::mix_m[q]) vo_mix[q] = (lane - SP::mix_j0[q]) * 4u;
     }
+    const bool l_w = lane < SP::mix_m[0];                // this lane holds a weight of mixer 0
 
     int pp_state = 0, pp_hsize = lost0;                // PostProcessor (PostProcessor.cs:12-16)
     uint32_t pp_len = 0;
@@ -527,21 +539,15 @@ __device__ void c3_decoder(const ZhLaunch &L, LDS &S, uint32_t lane) {
     InBuf in;
     in.stream = L.in; in.total = L.in_total; in.cbase = 0; in.k = 0; in.avail = 0; in.cur = 0;
 
-    // [bit] -> what was requested three bits before it: weights of candidate rows 0-3 | 4-7 per mixer; max, sse 20: the
-    // four candidate row pairs.  (Vectors indexed by the unrolled bit number: they stay in registers.)
-    typedef int v8i_ __attribute__((ext_vector_type(8)));
-    typedef uint32_t v8u_ __attribute__((ext_vector_type(8)));
-    v8i_ W0a = 0, W0b = 0, W1a = 0, W1b = 0;
-    v8u_ R20a = 0, R20b = 0, R20c = 0, R20d = 0;
-    auto setW = [&](uint32_t q, int b, int h, int v) __attribute__((always_inline)) {
-      if (q == 0) { if (h == 0) W0a[b] = v; else W0b[b] = v; } else { if (h == 0) W1a[b] = v; else W1b[b] = v; }
-    };
-    auto getW = [&](uint32_t q, int b, int h) __attribute__((always_inline)) -> int {
-      return q == 0 ? (h == 0 ? W0a[b] : W0b[b]) : (h == 0 ? W1a[b] : W1b[b]);
-    };
-    auto setR = [&](int b, int k, uint32_t v) __attribute__((always_inline)) {
-      if (k == 0) R20a[b] = v; else if (k == 1) R20b[b] = v; else if (k == 2) R20c[b] = v; else R20d[b] = v;
-    };
+    int mw[2] = {0, 0};                                 // this lane's weight in the current row of each mixer
+    uint32_t mrow[2] = {0, 0};                          // max: arena offset of that row
+    // MIXLDS: block (context) whose rows are in S.mixblk[mpar]; whether it was there when the byte began; what was
+    // trained before it arrived
+    uint32_t mblk = 0, mpar = 0;
+    bool mres = true;
+    uint32_t wsrc = 0;                                  // LDS address of this lane's weight in row 0 of the source in use
+    int sv_w[2] = {0, 0};
+    uint32_t sv_c8[2] = {0, 0};
     uint32_t mx_h[2] = {0, 0}, mx_rb[2] = {0, 0};
     auto mix_set = [&](uint32_t q, uint32_t hq) __attribute__((always_inline)) {
       mx_h[q] = uni(hq);
@@ -579,25 +585,36 @@ __device__ void c3_decoder(const ZhLaunch &L, LDS &S, uint32_t lane) {
       return (int)(v << 20) >> 20;
     };
 
-    // what the first three bits of a byte use (c8 = 1; 2-3; 4-7), requested when the byte's contexts are known
-    auto byte_start_loads = [&](bool staged, uint32_t lo) __attribute__((always_inline)) {
+    uint32_t row20 = 0;
+    // what bit 0 of a byte uses (c8 = 1), once the byte's contexts are known; lo = low nibble of the byte before
+    auto byte_start_rows = [&](bool staged, uint32_t lo) __attribute__((always_inline)) {
+      if constexpr (MIXLDS) {
+        const uint32_t blk = uni(mx_h[0] & mx_size1[0] & ~255u);
+        mres = uni(blk == mblk ? 1u : 0u) != 0u;
+        if (!mres) { mblk = blk; mpar ^= 1u; }
+        mpar = uni(mpar); mblk = uni(mblk);
+        wsrc = (mres ? lds_off(&S.mixblk[mpar][0]) : lds_off(&S.mixrow8[lo][0])) + lane * 4u;
+        const int w = *(lds_u32_p)(wsrc + 7u * 4u);
+        mw[0] = l_w ? w : 0;
+      } else {
 #pragma unroll
-      for (uint32_t q = 0; q < SP::nmix; ++q) {
-        if (staged) setW(q, 0, 0, (rr == 0 && lw < SP::mix_m[q]) ? (int)S.mixst[HELP == 1 ? q : 0][lo][lw] : 0);
-        else setW(q, 0, 0, (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_w1[q], mix_row(q, 1u), 0));
-        setW(q, 1, 0, (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_w2[q], mix_row(q, 2u), 0));
-        setW(q, 2, 0, (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_w4[q], mix_row(q, 4u), 0));
+        for (uint32_t q = 0; q < SP::nmix; ++q) {
+          mrow[q] = mix_row(q, 1u);
+          if (staged) { const uint32_t jj = lane - SP::mix_j0[q]; mw[q] = jj < SP::mix_m[q] ? (int)S.mixst[HELP == 1 ? q : 0][lo][jj & 15u] : 0; }
+          else mw[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow[q], 0);
+        }
       }
-      if (SP::has_tail) {
-        row18 = row18_load(1u);
-        setR(0, 0, row20_load(0u)); setR(1, 0, row20_load(2u));
-        setR(2, 0, row20_load(4u)); setR(2, 1, row20_load(6u));
-        a19i = 1u; w19 = uni((uint32_t)S.a19[1]);
-      }
+      if (SP::has_tail) { row18 = row18_load(1u); row20 = row20_load(1u); a19i = 1u; w19 = uni((uint32_t)S.a19[1]); }
     };
 #pragma unroll
     for (uint32_t q = 0; q < SP::nmix; ++q) mix_set(q, 0u);      // first byte of the block (h[] = 0)
-    byte_start_loads(false, 0u);
+    if constexpr (MIXLDS) {                              // ... whose block is the freshly initialised one (Predictor.cs:141-143)
+      const uint32_t w0 = 65536u / SP::mix_m[0];
+      for (uint32_t i = lane; i < 1792u; i += 64) S.mixblk[0][i] = w0;
+      if (lane == 0) S.mb_blk = 0;
+      c2_wave_sync();
+    }
+    byte_start_rows(false, 0u);
 
     int failed = 0;
     uint64_t tbyte = 0, tlast = 0;
@@ -644,36 +661,44 @@ __device__ void c3_decoder(const ZhLaunch &L, LDS &S, uint32_t lane) {
           uint32_t c8 = 1;
 #pragma unroll
           for (int bit = 0; bit < 8; ++bit) {
-            const bool pre_mx = bit != 7;                // the next bit stays in this byte
+            const bool pre_mx = bit != 7;                // the next bit stays in this byte: fetch both of its mixer rows
             c8 = uni(c8);
-            if (bit + 3 < 8) {                           // rows of the bit three ahead, all 8 candidates
+            int mwc0[2] = {0, 0}, mwc1[2] = {0, 0};
+            uint32_t mrow0[2] = {0, 0}, mrow1[2] = {0, 0};
+            if constexpr (MIXLDS) {
+              if (bit == 2 && uni(mres ? 0u : 1u)) {
+                // from bit 3 on the rows come from the block the helper wave has been bringing in since the byte began
+                uint32_t v, spin = 0;
+                while ((((v = c2_ld(&S.mb_blk)) >> 1) ^ (bseq - 1u)) & 0x7FFFFFFFu) { if (++spin > kC3Spin) { helper_ok = false; break; } }
+                helper_ok = uni(helper_ok ? 1u : 0u) != 0u;
+                if (UNLIKELY(!helper_ok)) { pp_hsize = 0x4000; break; }
+                wsrc = lds_off(&S.mixblk[mpar][0]) + lane * 4u;
+                if (l_w) {                                 // what bits 0 and 1 trained meanwhile
+                  *(lds_u32_p)(wsrc + sv_c8[0] * 28u) = (uint32_t)sv_w[0];
+                  *(lds_u32_p)(wsrc + sv_c8[1] * 28u) = (uint32_t)sv_w[1];
+                }
+                asm volatile("" ::: "memory");
+              }
+              if (pre_mx) {
+                const uint32_t a0 = wsrc + c8 * 56u;       // rows 2 c8, 2 c8 + 1: 28 bytes apart
+                mwc0[0] = *(lds_u32_p)a0;
+                mwc1[0] = *(lds_u32_p)(a0 + 28u);
+              }
+            } else if (pre_mx) {
 #pragma unroll
               for (uint32_t q = 0; q < SP::nmix; ++q) {
-                const uint32_t r0 = mix_row(q, c8 * 8u);
-                setW(q, bit + 3, 0, (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_w4[q], r0, 0));
-                setW(q, bit + 3, 1, (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_w4[q], r0 + 4u * SP::mix_m[q] * 4u, 0));
-              }
-              if (SP::has_tail) {
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) setR(bit + 3, (int)k, row20_load(c8 * 8u + 2u * k));
+                mrow0[q] = mix_row(q, c8 * 2u);
+                mrow1[q] = mrow0[q] + SP::mix_m[q] * 4u;
+                mwc0[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow0[q], 0);
+                mwc1[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow1[q], 0);
               }
             }
-            uint32_t row18n = 0, w19n0 = 0, w19n1 = 0;
+            uint32_t row18n = 0, row20n = 0, w19n0 = 0, w19n1 = 0;
             if (SP::has_tail && pre_mx) {
               row18n = row18_load(c8 * 2u);
+              row20n = row20_load(c8 * 2u);
               const uint32_t wp = *(lds_u32_p)(lds_off(S.a19) + ((c8 * 2u) & 254u) * 2u);
               w19n0 = uni(wp) & 0xffffu; w19n1 = uni(wp) >> 16;
-            }
-            // the candidate that came true: row r of this bit's generation = register r >> 2, DPP row r & 3
-            const uint32_t rcand = bit == 0 ? 0u : bit == 1 ? (c8 & 1u) : bit == 2 ? (c8 & 3u) : (c8 & 7u);
-            const uint32_t rrc = rcand & 3u;
-            int mw[2] = {0, 0};
-#pragma unroll
-            for (uint32_t q = 0; q < SP::nmix; ++q) mw[q] = (rcand & 4u) ? getW(q, bit, 1) : getW(q, bit, 0);
-            uint32_t row20 = 0;
-            if (SP::has_tail) {
-              const uint32_t kp = bit < 2 ? 0u : bit == 2 ? ((c8 >> 1) & 1u) : ((c8 >> 1) & 3u);
-              row20 = kp == 0 ? R20a[bit] : kp == 1 ? R20b[bit] : kp == 2 ? R20c[bit] : R20d[bit];
             }
             // ---- the model wave's predictions for this bit
             bool okp = true;
@@ -689,9 +714,11 @@ __device__ void c3_decoder(const ZhLaunch &L, LDS &S, uint32_t lane) {
             int dtv18 = 0, dtv20 = 0;
             int pt = 0;                                  // max: the tail's predictions, one per lane (15, 16, 17, 19, 21 -> lanes 0..4)
             if constexpr (SP::id == 3) {
-              const uint32_t ln = rrc * 16u + 15u;         // last lane of the row that came true
+              const uint32_t ln = 15u;
+              const uint32_t lw = lane;
+              p = lane < 16u ? p : 0;                     // (the predictions are replicated over the DPP rows)
               const int w1hi = mw[1] >> 8;
-              int t0 = __mul24(mw[0] >> 8, p);            // (component 15 itself publishes 0: lane l = 15 adds nothing)
+              int t0 = __mul24(mw[0] >> 8, p);            // (component 15 itself publishes 0: lane 15 adds nothing)
               int t1 = lw == 15u ? 0 : __mul24(w1hi, p);
               t0 += dpp_shr(t0, 1); t1 += dpp_shr(t1, 1);
               t0 += dpp_shr(t0, 2); t1 += dpp_shr(t1, 2);
@@ -721,7 +748,7 @@ __device__ void c3_decoder(const ZhLaunch &L, LDS &S, uint32_t lane) {
               int term = __mul24(mw[0] >> 8, p);         // lanes that do not feed the mixer hold weight 0
               term += dpp_shr(term, 1); term += dpp_shr(term, 2); term += dpp_shr(term, 4);
               if (SP::mix_m[0] > 8) term += dpp_shr(term, 8);
-              pt = med3i((int)rdlane((uint32_t)term, rrc * 16u + (SP::mix_m[0] > 8 ? 15u : 7u)) >> 8, -2048, 2047);   // wave-uniform
+              pt = med3i((int)rdlane((uint32_t)term, SP::mix_m[0] > 8 ? 15u : 7u) >> 8, -2048, 2047);   // wave-uniform
             }
             // ---- decode
             uint32_t ps;
@@ -750,7 +777,11 @@ __device__ void c3_decoder(const ZhLaunch &L, LDS &S, uint32_t lane) {
             for (uint32_t q = 0; q < SP::nmix; ++q) {
               const int eq = __mul24(SP::id == 3 ? (int)rdlane((uint32_t)e, q) : e, mx_rate[q]) >> 4;
               const int nmw = med3i(mw[q] + ((__mul24(eq, p) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
-              __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw, rsrc, rr == rrc ? vo_l[q] : kOob, mix_row(q, c8), 0);
+              __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw, rsrc, vo_mix[q], MIXLDS ? mix_row(q, c8) : uni(mrow[q]), 0);
+              if constexpr (MIXLDS) {                     // ... and the copy in LDS (a byte that keeps the context re-reads it from there)
+                if (mres || bit >= 2) { if (l_w) *(lds_u32_p)(lds_off(&S.mixblk[mpar][0]) + lane * 4u + c8 * 28u) = (uint32_t)nmw; }
+                else { sv_w[bit & 1] = nmw; sv_c8[bit & 1] = c8; }
+              }
             }
             if constexpr (SP::id == 3) {
               auto mix2_train = [&](int w, int rate, uint32_t ln, int pj_, int pk_) __attribute__((always_inline)) -> int {
@@ -776,8 +807,16 @@ __device__ void c3_decoder(const ZhLaunch &L, LDS &S, uint32_t lane) {
               w21 = mix2_train(w21, C2Max::rate21, 4, p19, p20);
             }
             c8 = c8 * 2u + y;
+            if (pre_mx) {
+#pragma unroll
+              for (uint32_t q = 0; q < SP::nmix; ++q) {
+                mw[q] = y ? mwc1[q] : mwc0[q];
+                if (MIXLDS) mw[q] = l_w ? mw[q] : 0;
+                else mrow[q] = uni(y ? mrow1[q] : mrow0[q]);
+              }
+            }
             if (SP::has_tail && pre_mx) {
-              row18 = row18n;
+              row18 = row18n; row20 = row20n;
               w19 = y ? w19n1 : w19n0; a19i = c8 & 255u;
             }
             yprev = y;
@@ -840,7 +879,7 @@ __device__ void c3_decoder(const ZhLaunch &L, LDS &S, uint32_t lane) {
 #pragma unroll
           for (uint32_t q = 0; q < SP::nmix; ++q) mix_set(q, S.hspec[SP::mix_lane[q] & ((1u << SP::hh) - 1u)][lo]);
           if (SP::has_tail) t_h20 = uni(S.hspec[SP::has_tail ? 20 : 0][lo]);
-          byte_start_loads(HELP == 1, lo);
+          byte_start_rows(HELP == 1, lo);
         }
         ++bseq;
       }
@@ -904,7 +943,7 @@ __device__ __forceinline__ void decode_chain3_body(const ZhLaunch &L, LDS &S) {
 #endif
 #define ZH_CHAIN3_KERNEL(name, spec, speculate, prof)                                  \
   extern "C" __global__ __launch_bounds__(192) void name(ZhLaunch L) {                 \
-    typedef C2LdsT<spec::has_tail, spec::helper> Lds;                                  \
+    typedef C2LdsT<spec::has_tail, spec::helper, spec::id == 2> Lds;                   \
     __shared__ Lds S;                                                                  \
     decode_chain3_body<spec, speculate, prof, Lds>(L, S);                              \
   }
