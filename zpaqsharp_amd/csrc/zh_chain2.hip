@@ -447,12 +447,6 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
       }
 
       for (;;) {                                       // one decoded byte per iteration
-        // Everything the per-byte control flow tests is one value for the wave; said so here, once per byte, so that
-        // the branches below are scalar branches and not exec-mask regions with their register copies.
-        pp_state = (int)uni((uint32_t)pp_state); pp_hsize = (int)uni((uint32_t)pp_hsize); pp_len = uni(pp_len); pnative = uni(pnative);
-        ob.len = uni64(ob.len); ob.stored = uni64(ob.stored); ob.room = uni(ob.room); ob.word = uni(ob.word);
-        in.k = uni(in.k); in.avail = uni(in.avail); in.cbase = uni64(in.cbase);
-        bseq = uni(bseq);
         // ---- Decoder.decompress prologue (Decoder.cs:36-45)
         if (UNLIKELY(d.curr == 0)) {
           uint32_t cu = 0;
