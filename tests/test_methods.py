@@ -139,3 +139,77 @@ def test_generated_zpaql_translations_are_current():
             continue
         free = set(pc + 1 for pc in gen.free_immediates(code))
         assert tuple(None if i in free else b for i, b in enumerate(code)) in skeletons, mt
+
+
+# ---- the wave-wide store / LZ77 kernel (zh_store.hip) ------------------------------------------------------------------
+def test_cpp_preprocessors_write_the_reference_formats():
+    """zpaqgen's fast LZ77 / BWT pre-processors (benchmark streams) against the oracle's run of the reference's
+    post-processor programs: the formats of LZBuffer.cs:96-115."""
+    from zpaqsharp_amd import synth
+    rng = np.random.default_rng(11)
+    datas = [util.text(70000, seed=3), bytes(rng.integers(0, 256, 5000, dtype=np.uint8)), b"ab" * 40000, b"", b"x"]
+    for mt in ("x0,1,4,0,3,16", "x6,1,4,0,3,24", "x0,2,12,0,7,16", "x0,2,3,0,7,16", "x0,3"):
+        model, args = methods.model_of(mt)
+        for d in datas:
+            pre = synth.preprocess(args, d)
+            assert oracle.run_pcomp(model.pcomp, pre, model.header[4], model.header[5], cap=len(d) + 64) == d, (mt, len(d))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["x2,1,4,0,3,22", "x6,1,4,0,3,24", "x2,2,12,0,7,22", "x2,2,3,0,7,22"])
+def test_store_kernel_on_big_distinct_blocks(ctx, method):
+    """Blocks of several stored chunks (a chunk header in the middle of a bit-packed code), output past the LDS ring,
+    matches from further back than the ring (a block that repeats itself after 1.5 MiB), every block distinct."""
+    from zpaqsharp_amd import synth
+    model, args = methods.model_of(method)
+    s, offs = synth.method_stream(model, args, "T", 6, 700_000, threads=4)
+    want = b"".join(synth.plain("T", b, 700_000).tobytes() for b in range(6))
+    assert ctx.decompress(s, out_cap=len(want), verify_sha1=True).tobytes() == want
+    assert ctx.stats().launches == 1                                   # (nothing was handed back to the generic kernel)
+    base = util.text(1_500_000, seed=77)
+    far = base + base[:900_000] + bytes(reversed(base[:300_000])) + base[200_000:1_400_000]     # distances of 1.5 and 2.7 MiB
+    pre = synth.preprocess(args, far)
+    blk = methods.compress_block(method, far, pre=pre)
+    assert oracle.decompress(blk, cap=len(far) + 16) == far
+    assert ctx.decompress(blk, verify_sha1=True).tobytes() == far
+    assert ctx.stats().launches == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["x0,1,4,0,3,16", "x0,2,12,0,7,16"])
+def test_store_kernel_when_the_window_wraps(ctx, method):
+    """A block longer than the program's M array (2^20 bytes here; no encoder of the reference writes one): distances
+    are taken modulo the array like the program does — the result is NOT the plaintext, it is what the oracle gives."""
+    from zpaqsharp_amd import synth
+    model, args = methods.model_of(method)
+    base = util.text(1_500_000, seed=78)
+    data = base + base[:900_000] + base[300_000:1_200_000]
+    blk = methods.compress_block(method, data, pre=synth.preprocess(args, data))
+    want = oracle.decompress(blk, cap=len(data) + 16)
+    assert len(want) == len(data) and want != data
+    assert ctx.decompress(blk).tobytes() == want
+    assert ctx.stats().launches == 1
+
+
+@pytest.mark.gpu
+def test_store_kernel_hands_back_what_it_does_not_take(ctx):
+    """Programs that are not the reference's LZ77 ones (E8E9 variants, BWT, an operand changed), damaged chunks: the
+    block runs on the generic kernel in the same call (zpaqhip_stats.launches counts the second launch)."""
+    d = util.text(30000, seed=5)
+    for method in ("x0,5,4,0,3,16", "x0,3"):
+        s = methods.compress_block(method, d)
+        assert ctx.decompress(s, verify_sha1=True).tobytes() == d
+        assert ctx.stats().launches == 2, method
+    # lzpre with one operand changed (a> 254 instead of a> 255 at the top): same structure, another program
+    model, args = methods.model_of("x0,2,12,0,7,16")
+    pc = bytearray(model.pcomp)
+    assert pc[1] == 255
+    pc[1] = 254
+    pre = methods.preprocess(d, args)
+    dec = bytes([1, len(pc) & 255, len(pc) >> 8]) + bytes(pc) + pre
+    body = len(dec).to_bytes(4, "big") + dec + b"\0\0\0\0"
+    tag = bytes([0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3])
+    s = tag + b"zPQ" + bytes([2, 1]) + model.header + b"\x01\0" + str(len(d)).encode() + b"\0\0" + body + b"\xfe\xff"
+    want = oracle.decompress(s, cap=len(d) + 16)
+    assert ctx.decompress(s).tobytes() == want
+    assert ctx.stats().launches == 2

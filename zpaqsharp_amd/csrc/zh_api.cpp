@@ -28,6 +28,7 @@ extern "C" hipError_t zh_launch_chain2(const ZhLaunch *L, uint32_t grid, hipStre
 extern "C" int zh_chain2_has(uint32_t spec);
 extern "C" hipError_t zh_launch_chain3(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int variant);
 extern "C" int zh_chain3_has(uint32_t spec);
+extern "C" hipError_t zh_launch_store(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 
 
 using namespace zh;
@@ -224,6 +225,11 @@ struct zh_pending {
   std::vector<uint8_t> code;
   std::vector<ZhSegDesc> sd;
   std::vector<ZhBlockDesc> bd_sorted;
+  // zh_store.hip hands blocks it does not take (ZH_E_RETRY) back: they run on the generic kernel in decode_finish
+  bool has_store = false;
+  ZhLaunch store_launch{};
+  size_t store_base = 0, store_count = 0;
+  uint32_t store_slots = 0;
 };
 
 static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, size_t in_len,
@@ -297,6 +303,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
   auto family = [&](size_t k) -> uint32_t {
     uint32_t f = models[bd[k].model].kind & 255u;
     if (opts.kernel == 1) f = ZH_FAM_GENERIC;              // force the generic kernel
+    if (f == ZH_FAM_STORE && (opts.reserved[1] == kPpOnlyMagic)) f = ZH_FAM_GENERIC;
     if (opts.kernel == 3 && f == ZH_FAM_CM1) f = ZH_FAM_CHAIN;   // force the lane-per-component kernel
     if (opts.kernel == 4 && f > ZH_FAM_CHAIN) f = ZH_FAM_CHAIN;  // lane-per-component kernel without model specialisation
     return f;
@@ -371,7 +378,11 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     L.flags = opts.reserved[1] == kPpOnlyMagic ? ZH_LAUNCH_PP_ONLY : 0u;
     const bool prof = getenv("ZPAQHIP_PROF") != nullptr;   // diagnostic build with in-kernel stamps
     if (prof) L.debug = (uint64_t *)((uint8_t *)c->queue.p + kQueueBytes);
-    if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, slots_of[g], stream));
+    if (g == ZH_FAM_STORE) {
+      HIPCHK(zh_launch_store(&L, slots_of[g], stream));
+      P.has_store = true; P.store_launch = L; P.store_base = base_of[g]; P.store_count = groups[g].size(); P.store_slots = slots_of[g];
+    }
+    else if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, slots_of[g], stream));
     else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, slots_of[g], stream));
     else if (g > ZH_FAM_CHAIN && zh_chain3_has(g - ZH_FAM_CHAIN) && (opts.kernel == 7 || opts.kernel == 8))   // decoder ‖ model ‖ helper wave (zh_chain3.hip): opt-in
       HIPCHK(zh_launch_chain3(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof ? 2 : opts.kernel == 7));
@@ -385,7 +396,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     else HIPCHK(zh_launch_generic(&L, slots_of[g], stream));
     ++launches;
     slots = std::max(slots, slots_of[g]);
-    kind_used = std::max(kind_used, std::min(g, (uint32_t)ZH_FAM_CHAIN) + 1);
+    kind_used = std::max(kind_used, g == ZH_FAM_STORE ? 1u : std::min(g, (uint32_t)ZH_FAM_CHAIN) + 1);
   }
   HIPCHK(hipEventRecord(c->ev1, stream));
   P.total_in = total_in; P.total_model = total_model;
@@ -419,6 +430,31 @@ static int decode_finish(zpaqhip_ctx *c, zh_pending &P, zpaqhip_seg_result *resu
   HIPCHK(hipStreamSynchronize(stream));
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  uint32_t extra_launches = 0;
+  if (P.has_store) {
+    // blocks the store kernel handed back (programs other than the reference's LZ77 ones, damaged chunks): the generic
+    // kernel is the complete implementation.  Same arena slots, same output places.
+    std::vector<ZhBlockDesc> redo;
+    for (size_t k = 0; k < P.store_count; ++k) {
+      const ZhBlockDesc &b = P.bd_sorted[P.store_base + k];
+      if (b.n_seg && res[b.first_seg].status == ZH_E_RETRY) redo.push_back(b);
+    }
+    if (!redo.empty()) {
+      ZhLaunch L = P.store_launch;
+      HIPCHK(hipMemcpyAsync((void *)L.blocks, redo.data(), redo.size() * sizeof(ZhBlockDesc), hipMemcpyHostToDevice, stream));
+      HIPCHK(hipMemsetAsync(L.queue, 0, 32, stream));
+      L.n_blocks = (uint32_t)redo.size();
+      HIPCHK(hipEventRecord(c->ev0, stream));
+      HIPCHK(zh_launch_generic(&L, std::min<uint32_t>(P.store_slots, L.n_blocks), stream));
+      HIPCHK(hipEventRecord(c->ev1, stream));
+      HIPCHK(hipMemcpyAsync(res.data(), c->results.p, n_segs * sizeof(ZhSegResult), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      float ms2 = 0;
+      HIPCHK(hipEventElapsedTime(&ms2, c->ev0, c->ev1));
+      ms += ms2;
+      ++extra_launches;
+    }
+  }
 
   int first_bad = ZPAQHIP_OK;
   uint64_t total_out = 0;
@@ -450,7 +486,7 @@ static int decode_finish(zpaqhip_ctx *c, zh_pending &P, zpaqhip_seg_result *resu
   c->stats.in_bytes = total_in;
   c->stats.out_bytes = total_out;
   c->stats.model_bytes = total_model;
-  c->stats.launches = launches;
+  c->stats.launches = launches + extra_launches;
   c->stats.concurrent = slots;
   c->stats.kernel_kind = kind_used;
   return first_bad;

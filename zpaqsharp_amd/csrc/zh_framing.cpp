@@ -426,6 +426,7 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
     }
     m.depth = depth;
     m.kind = (ok && units <= 64 && nmix <= 4 && m.arena_bytes < (1ull << 32)) ? ZH_FAM_CHAIN : ZH_FAM_GENERIC;
+    if (m.n == 0) m.kind = ZH_FAM_STORE;                  // stored bytes: the wave-wide store / LZ77 kernel (zh_store.hip)
   }
   // ---- specialisation the kernels may use (never changes results)
   if ((m.kind & 255u) == ZH_FAM_CHAIN) {

@@ -26,7 +26,8 @@ enum ZhCompType : uint8_t {  // LibZPAQ.cs:51-63
 #define ZH_FAM_GENERIC 0u        // zh_generic.hip
 #define ZH_FAM_CM1 1u            // zh_cm.hip: n == 1, one CM with >= 9 size bits
 #define ZH_FAM_CHAIN 2u          // zh_chain.hip: lane-per-component, n <= 64; +1/+2/+3 = specialised for min/mid/max
-#define ZH_NFAM 6u
+#define ZH_FAM_STORE 6u         // zh_store.hip: n == 0 (stored bytes, the post-processor is the whole work)
+#define ZH_NFAM 7u
 #define ZH_HK_GENERIC 0u         // interpret HCOMP
 #define ZH_HK_SHIFT 1u           // HCOMP == "a<<= K  *d=a  halt" with D == 0: H[0] = c << K
 
@@ -43,6 +44,7 @@ enum ZhCompType : uint8_t {  // LibZPAQ.cs:51-63
 #define ZH_E_BUDGET (-26)
 #define ZH_E_SKIPPED (-100)       // an earlier segment of the block failed
 #define ZH_E_STOPPED (-101)       // decode ended on request (ZH_LAUNCH_PP_ONLY); never leaves the library
+#define ZH_E_RETRY (-102)         // zh_store.hip hands the block to zh_generic.hip; never leaves the library
 #define ZH_LAUNCH_PP_ONLY 1u
 
 struct ZhComp {            // one component of a model (Component.cs:18-57 + header args)

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <memory>
 #include <string>
@@ -283,6 +284,139 @@ void e8e9_forward(uint8_t *buf, size_t n) {            // LibZPAQ.cs:372-384
     }
 }
 
+// ---------------------------------------------------------------------------
+// Pre-processors in the reference's code formats (LZBuffer.cs:96-115), for benchmark streams of its methods "1".."3":
+// only the FORMAT has to agree with the reference (the post-processors invert it); the parse is a plain greedy one
+// through a hash of the last position of every 4 (level 1) / m (level 2) bytes.
+// ---------------------------------------------------------------------------
+static int lg32(uint32_t x) { int r = 0; while (x) { ++r; x >>= 1; } return r; }   // floor(log2 x) + 1
+
+struct BitW {
+  std::vector<uint8_t> &v; uint64_t acc = 0; int n = 0;
+  explicit BitW(std::vector<uint8_t> &o) : v(o) {}
+  void put(uint32_t x, int bits) {                     // LSB first
+    if (!bits) return;
+    acc |= (uint64_t)(x & (bits == 32 ? 0xFFFFFFFFu : ((1u << bits) - 1))) << n; n += bits;
+    while (n >= 8) { v.push_back((uint8_t)acc); acc >>= 8; n -= 8; }
+  }
+  void flush() { if (n) { v.push_back((uint8_t)acc); acc = 0; n = 0; } }
+};
+
+template <class Lit, class Match>
+static void greedy_parse(const uint8_t *d, size_t n, uint32_t min_match, uint32_t max_match, uint32_t max_off, Lit lit, Match match) {
+  const uint32_t hb = 20;
+  std::vector<uint32_t> last(1u << hb, 0xFFFFFFFFu);
+  auto hash = [&](size_t i) { uint32_t v; memcpy(&v, d + i, 4); return (v * 2654435761u) >> (32 - hb); };
+  size_t i = 0, lit0 = 0;
+  const uint32_t key = min_match < 4 ? 4 : min_match;
+  while (i + key <= n) {
+    const uint32_t h = hash(i);
+    const uint32_t j = last[h];
+    last[h] = (uint32_t)i;
+    uint32_t m = 0;
+    if (j != 0xFFFFFFFFu && i - j <= max_off) {
+      while (m < max_match && i + m < n && d[j + m] == d[i + m]) ++m;
+    }
+    if (m >= min_match) {
+      if (i > lit0) lit(lit0, i);
+      match(m, (uint32_t)(i - j));
+      for (size_t k = i + 1; k < i + m && k + 4 <= n; k += 2) last[hash(k)] = (uint32_t)k;
+      i += m; lit0 = i;
+    } else ++i;
+  }
+  if (n > lit0) lit(lit0, n);
+}
+
+// level 1 (lazy2's input): 00,n,L[n] literals; mm,mmm,n,ll,r,q matches (LZBuffer.cs:96-107)
+static void pre_lz1(const uint8_t *d, size_t n, const int *args, std::vector<uint8_t> &out) {
+  const int rb = args[0] > 4 ? args[0] - 4 : 0;
+  const uint32_t min_match = args[2] < 4 ? 4 : (uint32_t)args[2];
+  BitW w(out);
+  greedy_parse(d, n, min_match, 1u << 16, (1u << 23) - 1,
+    [&](size_t a, size_t b) {
+      const uint32_t litn = (uint32_t)(b - a);
+      int ll = lg32(litn) - 1;
+      w.put(0, 2);
+      while (ll > 0) { --ll; w.put(1, 1); w.put((litn >> ll) & 1, 1); }
+      w.put(0, 1);
+      for (size_t k = a; k < b; ++k) w.put(d[k], 8);
+    },
+    [&](uint32_t ln, uint32_t off) {
+      int ll = lg32(ln) - 1;
+      off += (1u << rb) - 1;
+      const int lo = lg32(off) - 1 - rb;
+      w.put((uint32_t)((lo + 8) >> 3), 2);
+      w.put((uint32_t)(lo & 7), 3);
+      while (ll > 2) { --ll; w.put(1, 1); w.put((ln >> ll) & 1, 1); }
+      w.put(0, 1);
+      w.put(ln & 3, 2);
+      w.put(off, rb);
+      w.put(off >> rb, lo);
+    });
+  w.flush();
+}
+
+// level 2 (lzpre's input): 00xxxxxx x+1 literals; yyxxxxxx y+1 offset bytes, length x+m (LZBuffer.cs:109-112)
+static void pre_lz2(const uint8_t *d, size_t n, const int *args, std::vector<uint8_t> &out) {
+  const uint32_t m = (uint32_t)args[2];
+  greedy_parse(d, n, m < 3 ? 3 : m, m + 63 + 4 * 64, (1u << 24) - 1,
+    [&](size_t a, size_t b) {
+      while (a < b) {
+        const size_t k = b - a < 64 ? b - a : 64;
+        out.push_back((uint8_t)(k - 1));
+        out.insert(out.end(), d + a, d + a + k);
+        a += k;
+      }
+    },
+    [&](uint32_t ln, uint32_t off) {
+      off -= 1;
+      while (ln > 0) {
+        const uint32_t len1 = ln > m * 2 + 63 ? m + 63 : ln > m + 63 ? ln - m : ln;
+        if (off < (1u << 16)) { out.push_back((uint8_t)(64 + len1 - m)); out.push_back((uint8_t)(off >> 8)); out.push_back((uint8_t)off); }
+        else { out.push_back((uint8_t)(128 + len1 - m)); out.push_back((uint8_t)(off >> 16)); out.push_back((uint8_t)(off >> 8)); out.push_back((uint8_t)off); }
+        ln -= len1;
+      }
+    });
+}
+
+// level 3 (bwtrle's input): BWT, end of string coded as 255, its position in the last 4 bytes (LZBuffer.cs:113-115, :228-240)
+static void pre_bwt(const uint8_t *d, size_t n, std::vector<uint8_t> &out) {
+  if (n == 0) { out.assign({255, 0, 0, 0, 0}); return; }
+  std::vector<uint32_t> sa(n);
+  // bucket by the first two bytes, then sort every bucket by plain suffix comparison (the end of the block is smaller than
+  // any byte): synthetic text repeats itself over tens of bytes at most
+  std::vector<uint32_t> cnt(65537, 0);
+  auto key2 = [&](size_t i) -> uint32_t { return (uint32_t)d[i] << 8 | (i + 1 < n ? d[i + 1] : 0u); };
+  for (size_t i = 0; i < n; ++i) ++cnt[key2(i) + 1];
+  for (size_t k = 1; k <= 65536; ++k) cnt[k] += cnt[k - 1];
+  { std::vector<uint32_t> pos(cnt.begin(), cnt.end() - 1); for (size_t i = 0; i < n; ++i) sa[pos[key2(i)]++] = (uint32_t)i; }
+  auto less = [&](uint32_t a, uint32_t b) {
+    if (a == b) return false;
+    const size_t la = n - a, lb = n - b, l = la < lb ? la : lb;
+    const int c = memcmp(d + a, d + b, l);
+    return c ? c < 0 : la < lb;
+  };
+  for (size_t k = 0; k < 65536; ++k)
+    if (cnt[k + 1] - cnt[k] > 1) std::sort(sa.begin() + cnt[k], sa.begin() + cnt[k + 1], less);
+  out.reserve(n + 5);
+  out.push_back(d[n - 1]);
+  uint32_t idx = 0;
+  for (size_t i = 1; i <= n; ++i) {
+    const uint32_t s0 = sa[i - 1];
+    if (s0 == 0) { idx = (uint32_t)i; out.push_back(255); } else out.push_back(d[s0 - 1]);
+  }
+  for (int k = 0; k < 4; ++k) out.push_back((uint8_t)(idx >> (8 * k)));
+}
+
+static void preprocess(const uint8_t *d, size_t n, const int *args, std::vector<uint8_t> &out) {
+  out.clear();
+  const int level = args[1] & 3;
+  if (level == 1) pre_lz1(d, n, args, out);
+  else if (level == 2) pre_lz2(d, n, args, out);
+  else if (level == 3) pre_bwt(d, n, out);
+  else out.assign(d, d + n);
+}
+
 struct Stream {
   std::vector<uint8_t> bytes;
   std::vector<uint64_t> offsets;                       // nblocks + 1
@@ -356,6 +490,90 @@ void *zpaqgen_stream_new(const uint8_t *hdr, size_t hdrlen, const uint8_t *pcomp
         char comment[32];
         snprintf(comment, sizeof comment, "%zu", block_size);
         if (w.write_block(o, pcomp, plen, src, block_size, "", comment, sha, true)) { failed = 1; break; }
+        parts[b].swap(o.v);
+      }
+    });
+  for (auto &t : th) t.join();
+  if (failed) { s->error = "stream generation failed"; return s; }
+  size_t total = 0;
+  for (auto &p : parts) total += p.size();
+  s->bytes.reserve(total);
+  for (auto &p : parts) {
+    s->offsets.push_back(s->bytes.size());
+    s->bytes.insert(s->bytes.end(), p.begin(), p.end());
+    std::vector<uint8_t>().swap(p);
+  }
+  s->offsets.push_back(s->bytes.size());
+  return s;
+}
+
+// What the pre-processor of a method makes of `data` (args[0..8] = the method's numbers, args[1] & 3 = level; the E8E9
+// variants expect the caller to have applied the forward transform).  Returns the size, or -20 with *need set.
+long zpaqgen_preprocess(const int *args, const uint8_t *data, size_t n, uint8_t *out, size_t cap, size_t *need) {
+  std::vector<uint8_t> v;
+  preprocess(data, n, args, v);
+  if (need) *need = v.size();
+  if (v.size() > cap) return ZPAQHIP_E_OUTPUT_FULL;
+  if (!v.empty()) memcpy(out, v.data(), v.size());
+  return (long)v.size();
+}
+
+// Synthetic stream of a METHOD (LibZPAQ.compressBlock's framing): every block's plaintext goes through the method's
+// pre-processor and is then coded with the model of `hdr` — or, for n = 0, stored in length-prefixed chunks
+// (Encoder.cs:39-73) behind the selector and the PCOMP program.
+void *zpaqgen_method_stream_new(const uint8_t *hdr, size_t hdrlen, const uint8_t *pcomp, size_t plen, const int *args, int kind,
+                                uint64_t first_block, uint32_t nblocks, size_t block_size, int threads) {
+  Stream *s = new Stream();
+  if (!zh::host_tables_ok()) { s->error = "table pins failed"; return s; }
+  const bool stored = hdrlen > 6 && hdr[6] == 0;
+  const bool doe8 = args[1] >= 4 && args[1] <= 7;
+  std::vector<std::vector<uint8_t>> parts(nblocks);
+  std::atomic<uint32_t> next{0};
+  std::atomic<int> failed{0};
+  if (threads < 1) threads = 1;
+  std::vector<std::thread> th;
+  for (int t = 0; t < threads; ++t)
+    th.emplace_back([&] {
+      BlockWriter w;
+      if (!stored && w.setup(hdr, hdrlen)) { failed = 1; return; }
+      std::vector<uint8_t> plain(block_size), enc, pre;
+      for (;;) {
+        uint32_t b = next.fetch_add(1);
+        if (b >= nblocks || failed) break;
+        gen_plain(kind, first_block + b, plain.data(), block_size);
+        uint8_t sha[20];
+        zh::sha1(plain.data(), block_size, sha);
+        const uint8_t *src = plain.data();
+        if (doe8) { enc = plain; e8e9_forward(enc.data(), enc.size()); src = enc.data(); }
+        preprocess(src, block_size, args, pre);
+        char comment[32];
+        snprintf(comment, sizeof comment, "%zu", block_size);
+        Out o;
+        if (!stored) {
+          o.v.reserve(pre.size() / 2 + 4096);
+          if (w.write_block(o, pcomp, plen, pre.data(), pre.size(), "", comment, sha, true)) { failed = 1; break; }
+        } else {
+          static const uint8_t kTag[13] = {0x37, 0x6b, 0x53, 0x74, 0xa0, 0x31, 0x83, 0xd3, 0x8c, 0xb2, 0x28, 0xb0, 0xd3};
+          o.v.reserve(pre.size() + plen + 4096);
+          o.put(kTag, 13);
+          o.put('z'); o.put('P'); o.put('Q'); o.put(2); o.put(1);      // n = 0 -> level 2 (Compressor.cs:92-96)
+          o.put(hdr, hdrlen);
+          o.put(1); o.put(0);
+          o.put(comment, strlen(comment));
+          o.put(0); o.put(0);
+          std::vector<uint8_t> dec;                                      // the decoded stream: selector [+ program] + data
+          if (pcomp && plen) { dec.push_back(1); dec.push_back((uint8_t)(plen & 255)); dec.push_back((uint8_t)(plen >> 8)); dec.insert(dec.end(), pcomp, pcomp + plen); }
+          else dec.push_back(0);
+          dec.insert(dec.end(), pre.begin(), pre.end());
+          for (size_t i = 0; i < dec.size(); i += 65536) {
+            const size_t k = dec.size() - i < 65536 ? dec.size() - i : 65536;
+            o.put((int)(k >> 24 & 255)); o.put((int)(k >> 16 & 255)); o.put((int)(k >> 8 & 255)); o.put((int)(k & 255));
+            o.put(dec.data() + i, k);
+          }
+          o.put(0); o.put(0); o.put(0); o.put(0);
+          o.put(253); o.put(sha, 20);
+          o.put(255);
+        }
         parts[b].swap(o.v);
       }
     });

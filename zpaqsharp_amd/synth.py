@@ -39,6 +39,10 @@ def load():
         L.zpaqgen_compress_block.restype = C.c_long
         L.zpaqgen_stream_new.argtypes = [vp, sz, vp, sz, C.c_int, C.c_int, C.c_uint64, C.c_uint32, sz, C.c_int]
         L.zpaqgen_stream_new.restype = vp
+        L.zpaqgen_preprocess.argtypes = [C.POINTER(C.c_int), vp, sz, vp, sz, C.POINTER(sz)]
+        L.zpaqgen_preprocess.restype = C.c_long
+        L.zpaqgen_method_stream_new.argtypes = [vp, sz, vp, sz, C.POINTER(C.c_int), C.c_int, C.c_uint64, C.c_uint32, sz, C.c_int]
+        L.zpaqgen_method_stream_new.restype = vp
         L.zpaqgen_stream_error.argtypes = [vp]
         L.zpaqgen_stream_error.restype = C.c_char_p
         L.zpaqgen_stream_size.argtypes = [vp]
@@ -154,6 +158,47 @@ def stream(model, kind: str = "T", nblocks: int = 1, block_size: int = 1 << 16, 
             raise RuntimeError(e.decode())
         out = np.empty(L.zpaqgen_stream_size(h), np.uint8)
         offs = np.zeros(nblocks + 1, np.uint64)
+        L.zpaqgen_stream_copy(h, out.ctypes.data, offs.ctypes.data)
+        return out, offs
+    finally:
+        L.zpaqgen_stream_free(h)
+
+
+def preprocess(args, data) -> bytes:
+    """What the pre-processor of a method (LZBuffer.cs:96-115 formats: level = args[1] & 3) makes of `data`: the fast C++
+    twin of tools/methods.preprocess for benchmark-sized inputs (same formats, its own greedy parse)."""
+    L = load()
+    d = _u8(data)
+    a = (C.c_int * 9)(*[int(x) for x in list(args)[:9]] + [0] * (9 - min(9, len(args))))
+    need = C.c_size_t(0)
+    out = np.empty(max(16, d.size + d.size // 8 + 64), np.uint8)
+    rc = L.zpaqgen_preprocess(a, d.ctypes.data if d.size else None, d.size, out.ctypes.data, out.size, C.byref(need))
+    if rc == -20:
+        out = np.empty(need.value, np.uint8)
+        rc = L.zpaqgen_preprocess(a, d.ctypes.data if d.size else None, d.size, out.ctypes.data, out.size, C.byref(need))
+    if rc < 0:
+        raise RuntimeError(f"zpaqgen_preprocess failed: {rc}")
+    return out[:rc].tobytes()
+
+
+def method_stream(model, args, kind: str = "T", nblocks: int = 1, block_size: int = 1 << 16, first_block: int = 0,
+                  threads: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """`nblocks` distinct blocks written with a METHOD of the reference (LibZPAQ.compressBlock framing): plaintext
+    generator `kind`, the method's pre-processor (args as tools/methods.make_config returns them), then the model of
+    `model` — stored chunks for n = 0.  Returns (stream, block offsets)."""
+    L = load()
+    hdr, pc = _u8(model.header), _u8(model.pcomp or b"")
+    a = (C.c_int * 9)(*[int(x) for x in list(args)[:9]] + [0] * (9 - min(9, len(args))))
+    if threads is None:
+        threads = min(32, os.cpu_count() or 1)
+    h = L.zpaqgen_method_stream_new(hdr.ctypes.data, hdr.size, pc.ctypes.data if pc.size else None, pc.size, a, KINDS[kind],
+                                    first_block, nblocks, block_size, threads)
+    try:
+        err = L.zpaqgen_stream_error(h)
+        if err:
+            raise RuntimeError(err.decode())
+        out = np.empty(L.zpaqgen_stream_size(h), np.uint8)
+        offs = np.empty(nblocks + 1, np.uint64)
         L.zpaqgen_stream_copy(h, out.ctypes.data, offs.ctypes.data)
         return out, offs
     finally:
