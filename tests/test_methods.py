@@ -156,7 +156,7 @@ def test_cpp_preprocessors_write_the_reference_formats():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("method", ["x2,1,4,0,3,22", "x6,1,4,0,3,24", "x2,2,12,0,7,22", "x2,2,3,0,7,22"])
+@pytest.mark.parametrize("method", ["x2,1,4,0,3,22", "x6,1,4,0,3,24", "x2,2,12,0,7,22", "x2,2,3,0,7,22", "x2,3"])
 def test_store_kernel_on_big_distinct_blocks(ctx, method):
     """Blocks of several stored chunks (a chunk header in the middle of a bit-packed code), output past the LDS ring,
     matches from further back than the ring (a block that repeats itself after 1.5 MiB), every block distinct."""
@@ -196,10 +196,10 @@ def test_store_kernel_hands_back_what_it_does_not_take(ctx):
     """Programs that are not the reference's LZ77 ones (E8E9 variants, BWT, an operand changed), damaged chunks: the
     block runs on the generic kernel in the same call (zpaqhip_stats.launches counts the second launch)."""
     d = util.text(30000, seed=5)
-    for method in ("x0,5,4,0,3,16", "x0,3"):
+    for method, launches in (("x0,5,4,0,3,16", 2), ("x0,7", 2), ("x0,3", 1), ("x5,3", 1)):      # E8E9 variants go back; the plain BWTs are taken
         s = methods.compress_block(method, d)
         assert ctx.decompress(s, verify_sha1=True).tobytes() == d
-        assert ctx.stats().launches == 2, method
+        assert ctx.stats().launches == launches, method
     # lzpre with one operand changed (a> 254 instead of a> 255 at the top): same structure, another program
     model, args = methods.model_of("x0,2,12,0,7,16")
     pc = bytearray(model.pcomp)
@@ -213,3 +213,18 @@ def test_store_kernel_hands_back_what_it_does_not_take(ctx):
     want = oracle.decompress(s, cap=len(d) + 16)
     assert ctx.decompress(s).tobytes() == want
     assert ctx.stats().launches == 2
+
+
+@pytest.mark.gpu
+def test_a_bwt_block_over_16_mib(ctx):
+    """Blocks over 16 MiB take the other list traversal of bwtrle (LibZPAQ.cs:741-795: plain positions in H instead of
+    position << 8 | byte): one real block of 17 MiB, written with the method's own configuration, decoded by the wave-wide
+    inverse BWT and checked against the plaintext and the stored SHA-1."""
+    from zpaqsharp_amd import synth
+    method = "x5,3"
+    model, args = methods.model_of(method)
+    n = 17 << 20
+    s, offs = synth.method_stream(model, args, "T", 1, n, threads=1)
+    got = ctx.decompress(s, out_cap=n, verify_sha1=True)
+    assert ctx.stats().launches == 1
+    assert np.array_equal(got, synth.plain("T", 0, n))

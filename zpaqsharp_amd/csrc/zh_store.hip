@@ -124,7 +124,11 @@ __device__ const uint8_t kLazy302[43] = {255, 8, 0, 1, 3, 0, 3, 2, 7, 3, 5, 1, 2
 __device__ const uint8_t kLazy337[51] = {255, 8, 0, 1, 3, 0, 3, 2, 7, 3, 5, 1, 2, 3, 1, 2, 1, 1, 1, 1, 1, 1, 2, 3, 2, 5,
                                           5, 0, 0, 0, 0, 2, 2, 1, 0, 0, 0, 3, 1, 1, 1, 1, 1, 1, 1, 4, 4, 7, 8, 8, 0};
 
-enum : uint32_t { kProgNone = 0, kProgLzpre = 1, kProgLazy2 = 2 };
+// bwtrle (LibZPAQ.cs:642-795), the two list traversals without E8E9: 16 MiB blocks at most / any size
+__device__ const uint8_t kBwt123[11] = {255, 8, 8, 8, 0, 255, 1, 255, 8, 0, 8};
+__device__ const uint8_t kBwt106[9] = {255, 8, 8, 8, 0, 255, 1, 255, 0};
+
+enum : uint32_t { kProgNone = 0, kProgLzpre = 1, kProgLazy2 = 2, kProgBwt = 3 };
 
 // ---------------------------------------------------------------------------------------------------------------
 // FLUSHER WAVE: ring -> Writer and M
@@ -475,6 +479,145 @@ __device__ __attribute__((noinline)) void lz_window(StoreLds &S, Lz &Z, uint32_t
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Inverse BWT of `bwtrle` (LibZPAQ.cs:642-795) for a well-formed block, wave-wide.
+//
+// The program collects the segment in M, and at its end: idx = the last 4 bytes, n = the rest; counts the bytes; builds
+// the list T[1 + #(bytes < c) + #(earlier c)] = b for every position b != idx with byte c (a stable counting sort by
+// byte value, slot 0 left to the end-of-string symbol, which sits at idx coded as 255); then walks it:
+// d = idx; while (d) { d = T[d]; out(M[d]); } — one dependent load per byte, 4 million in a row for a 4 MiB block.
+// Here:  (1) per-lane histograms of 64 contiguous chunks of M in LDS, (2) their prefix sums, (3) the stable scatter
+// T[pos] = b by chunk (T is the program's H array in the arena), (4) the walk cut at SPLITTERS — every position p with
+// (p - 1) % step == 0, a few thousand of them, and idx: every lane walks from one splitter to the next and notes where
+// it ended and after how many steps, lanes take splitters from a counter; one lane strings the pieces together from
+// idx (offsets = prefix sums of the lengths); a second walk writes every piece's bytes at its offset.  64 independent
+// chains per wavefront instead of one.
+// Taken only when the program would do exactly this: one segment in the block, 1 <= idx < n, M[idx] == 255 (so the
+// counts are those of a BWT), n + 256 <= |H| and n + 4 <= |M| (no wrap), and the walk from idx reaches 0 without a
+// cycle; anything else is left to the generic kernel (returns false).  *out_len = bytes the program would have written.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kSplitMax = 4096u;
+struct BwtLds {                                         // overlays StoreLds::ring (128 KiB)
+  uint32_t hist[256][64];                               // [byte][chunk]: counts, then first free list position (lanes side by side: no bank conflicts)
+  uint32_t s_len[kSplitMax + 1], s_next[kSplitMax + 1], s_off[kSplitMax + 1];   // per splitter (+ idx as the last one)
+  uint32_t total[256];
+  uint32_t counter, bad, out_total;
+};
+static_assert(sizeof(BwtLds) <= kRing, "the inverse BWT's tables live in the ring");
+
+__device__ __attribute__((noinline)) bool ibwt_block(StoreLds &S, const uint8_t *Mp, uint32_t *T, uint32_t n_in, uint64_t msize, uint64_t hsize,
+                                                     uint8_t *outp, uint64_t out_cap, uint32_t *out_len, uint32_t lane) {
+  BwtLds &B = *reinterpret_cast<BwtLds *>(S.ring);
+  if (n_in < 6u || (uint64_t)n_in > msize) return false;
+  const uint32_t n = n_in - 4u;
+  const uint32_t idx = uni((uint32_t)Mp[n] | (uint32_t)Mp[n + 1] << 8 | (uint32_t)Mp[n + 2] << 16 | (uint32_t)Mp[n + 3] << 24);
+  if (idx == 0u || idx >= n || (uint64_t)n + 256u > hsize || n >= 0x7FFFFFFFu) return false;
+  if (uni((uint32_t)Mp[idx]) != 255u) return false;
+  // ---- (1) histograms: lane l counts chunk l
+  const uint32_t ch = (n + 63u) / 64u, b0 = lane * ch, b1 = b0 + ch < n ? b0 + ch : n;
+  for (uint32_t c = 0; c < 256; ++c) B.hist[c][lane] = 0;
+  if (lane == 0) { B.counter = 0; B.bad = 0; B.out_total = 0; }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  for (uint32_t b = b0; b < b1; ++b) {
+    if (b == idx) continue;
+    const uint32_t c = Mp[b];
+    B.hist[c][lane] += 1u;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  // ---- (2) first list position of every (chunk, byte): 1 + #(bytes < c) + #(c in earlier chunks); lane l does bytes 4l..4l+3
+  for (uint32_t q = 0; q < 4; ++q) {
+    const uint32_t c = lane * 4u + q;
+    uint32_t sum = 0;
+    for (uint32_t l = 0; l < 64; ++l) sum += B.hist[c][l];
+    B.total[c] = sum;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  for (uint32_t q = 0; q < 4; ++q) {
+    const uint32_t c = lane * 4u + q;
+    uint32_t base = 1u;
+    for (uint32_t c2 = 0; c2 < c; ++c2) base += B.total[c2];
+    for (uint32_t l = 0; l < 64; ++l) { const uint32_t h = B.hist[c][l]; B.hist[c][l] = base; base += h; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  // ---- (3) the list: stable within a byte value (chunks in order, positions in order inside a chunk)
+  for (uint32_t b = b0; b < b1; ++b) {
+    if (b == idx) continue;
+    const uint32_t c = Mp[b];
+    const uint32_t pos = B.hist[c][lane];
+    B.hist[c][lane] = pos + 1u;
+    T[pos] = b;
+  }
+  if (lane == 0) T[0] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  __builtin_amdgcn_s_waitcnt(0);
+  // ---- (4) the walk, cut at the splitters
+  uint32_t step = 1u;
+  while ((uint64_t)step * kSplitMax < (uint64_t)n) step <<= 1;
+  const uint32_t nsplit = (n - 1u + step - 1u) / step;  // grid positions 1, 1 + step, ... below n
+  const uint32_t smask = step - 1u;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (lane == 0) B.counter = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // every lane walks a piece; a lane that ends one takes the next splitter at once (the wave iterates while any lane
+    // has work: pieces differ a lot in length)
+    bool busy = false, finished = false;
+    uint32_t i = 0, p = 0, cnt = 0, off = 0;
+    while (__ballot(!finished) != 0) {
+      if (!busy && !finished) {
+        i = atomicAdd(&B.counter, 1u);                    // (the last index: idx itself)
+        if (i > nsplit) finished = true;
+        else {
+          p = i == nsplit ? idx : 1u + i * step;
+          cnt = 0;
+          off = pass ? B.s_off[i] : 0u;
+          if (i != nsplit && p == idx) { if (pass == 0) { B.s_len[i] = 0; B.s_next[i] = 0xFFFFFFFFu; } }   // (idx is the last splitter)
+          else if (pass == 1 && off == 0xFFFFFFFFu) {}                                              // (not on the way from idx)
+          else busy = true;
+        }
+      }
+      if (busy) {
+        p = __builtin_nontemporal_load(&T[p]);
+        if (pass) { const uint8_t v = Mp[p]; if ((uint64_t)off + cnt < out_cap) outp[off + cnt] = v; }
+        ++cnt;
+        uint32_t nxt = 0xFFFFFFFDu;
+        if (p == 0u) nxt = 0xFFFFFFFEu;                                // the end of the text
+        else if (p == idx) nxt = nsplit;
+        else if (((p - 1u) & smask) == 0u) nxt = (p - 1u) / step;
+        else if (cnt > n) { B.bad = 1u; nxt = 0xFFFFFFFFu; }          // (a cycle: not a BWT)
+        if (nxt != 0xFFFFFFFDu) {
+          if (pass == 0) { B.s_len[i] = cnt; B.s_next[i] = nxt; }
+          busy = false;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    if (pass == 0) {
+      // one lane strings the pieces together from idx
+      for (uint32_t i = lane; i <= nsplit; i += 64) B.s_off[i] = 0xFFFFFFFFu;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      if (lane == 0) {
+        uint32_t i = nsplit, off = 0, hops = 0;
+        for (;;) {
+          if (B.s_off[i] != 0xFFFFFFFFu || ++hops > nsplit + 2u) { B.bad = 1u; break; }      // a piece twice: a cycle
+          B.s_off[i] = off;
+          off += B.s_len[i];
+          const uint32_t nx = B.s_next[i];
+          if (nx == 0xFFFFFFFEu) break;
+          if (nx == 0xFFFFFFFFu) { B.bad = 1u; break; }
+          i = nx;
+        }
+        B.out_total = off;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      if (uni(B.bad)) return false;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  __builtin_amdgcn_s_waitcnt(0);
+  *out_len = uni(B.out_total);
+  return true;
+}
 }  // namespace
 
 extern "C" __global__ __launch_bounds__(128) void zh_decode_store(ZhLaunch L) {
@@ -507,7 +650,7 @@ extern "C" __global__ __launch_bounds__(128) void zh_decode_store(ZhLaunch L) {
     uint32_t seg_base = 0;                              // ... when the segment began: the program's ptr = wp - seg_base
     int pp_state = 0, pp_hsize = 0;                      // PostProcessor (PostProcessor.cs:12-16)
     uint32_t pp_len = 0, prog = kProgNone;
-    uint32_t minlen = 0, rb = 0;
+    uint32_t minlen = 0, rb = 0, bw_n = 0;               // (bwtrle: bytes of the segment collected in M)
     bool retry = false, failed = false, lost = false;
     uint32_t fpos_seen = 0;                             // last value read from the flusher
 
@@ -568,7 +711,7 @@ extern "C" __global__ __launch_bounds__(128) void zh_decode_store(ZhLaunch L) {
         pp_state = (int)uni((uint32_t)pp_state); prog = uni(prog);
         wp = uni(wp); wpub = uni(wpub); r.left = uni(r.left);
         r.in.k = uni(r.in.k); r.in.avail = uni(r.in.avail); r.in.cbase = uni64(r.in.cbase); r.kdisc = uni(r.kdisc);
-        rb = uni(rb); minlen = uni(minlen); fpos_seen = uni(fpos_seen); seg_base = uni(seg_base);
+        rb = uni(rb); minlen = uni(minlen); fpos_seen = uni(fpos_seen); seg_base = uni(seg_base); bw_n = uni(bw_n);
         if (UNLIKELY(lost)) break;
         if (UNLIKELY(wp > 0xF0000000u)) { retry = true; break; }      // (positions are 32 bits)
         if (wp - wpub >= 1024u && pp_state == 5) publish();            // the flusher follows in steps of 1 KiB
@@ -595,6 +738,34 @@ extern "C" __global__ __launch_bounds__(128) void zh_decode_store(ZhLaunch L) {
           r.left = 0;
           rd_seek(r, S, from + n, lane);
           continue;
+        }
+        // ---- bwtrle: the segment is collected in M (`*b=a b++`), the inverse BWT runs at its end
+        if (pp_state == 5 && prog == kProgBwt) {
+          if (!eos) {
+            const uint64_t from = in_pos(r.in);
+            const uint32_t n = r.left;
+            if ((uint64_t)bw_n + n > (uint64_t)mmask + 1u) { retry = true; break; }      // (M would wrap)
+            uint8_t *Mw = slot + uni64(Mo->pm_off);
+            for (uint32_t base = 0; base < n; base += 256) {
+              uint32_t v[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { const uint32_t j = base + 64u * k + lane; v[k] = j < n ? L.in[from + j] : 0u; }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { const uint32_t j = base + 64u * k + lane; if (j < n) Mw[bw_n + j] = (uint8_t)v[k]; }
+            }
+            bw_n += n;
+            r.left = 0;
+            rd_seek(r, S, from + n, lane);
+            continue;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+          __builtin_amdgcn_s_waitcnt(0);
+          uint32_t produced_b = 0;
+          const bool okb = n_seg == 1u && ibwt_block(S, Mp, reinterpret_cast<uint32_t *>(slot + uni64(Mo->ph_off)), bw_n, (uint64_t)mmask + 1u,
+                                                     1ull << uni(Mo->ph), outp, b_out_cap, &produced_b, lane);
+          if (!okb) { retry = true; break; }
+          wp += produced_b;
+          break;
         }
         // ---- a program: the bytes of the window, as long as the chunk and the window last (lz_window)
         if (pp_state == 5 && !eos) {
@@ -664,6 +835,13 @@ extern "C" __global__ __launch_bounds__(128) void zh_decode_store(ZhLaunch L) {
               }
               prog = kProgLazy2;
             }
+            else if (id == ZH_PCOMP_BWTRLE_123 || id == ZH_PCOMP_BWTRLE_106) {
+              ok = true;
+              const int nk = id == ZH_PCOMP_BWTRLE_123 ? 11 : 9;
+              for (int k = 0; k < nk; ++k) ok = ok && S.words[k] == (id == ZH_PCOMP_BWTRLE_123 ? kBwt123[k] : kBwt106[k]);
+              ok = ok && uni(Mo->ph) <= 31u;
+              prog = kProgBwt;
+            }
             ok = uni(ok ? 1u : 0u) != 0u;
             // every other program (and an M that 32 bits of mask cannot address) is the generic kernel's
             if (!ok || pmb > 31u) { retry = true; break; }
@@ -687,7 +865,7 @@ extern "C" __global__ __launch_bounds__(128) void zh_decode_store(ZhLaunch L) {
 
       // ---- end of the segment: everything out of the ring before the results are written and M is read again
       if (flusher_on && !lost) {
-        if (pp_state == 1) { st_put0(&S.skip_to, wp); wait_flushed(wp); }     // (PASS wrote the Writer itself)
+        if (pp_state == 1 || prog == kProgBwt) { st_put0(&S.skip_to, wp); wait_flushed(wp); }     // (PASS and the inverse BWT wrote the Writer themselves)
         else flush_all();
       }
       if (retry || lost) break;
