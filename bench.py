@@ -15,10 +15,13 @@ N > 1 (BASELINE configs[3] layout): ONE shared stream and ONE block table.  Ever
 rank writes 1/N of the blocks; the pieces are all-gathered into the shared stream
 (every rank holds it in HBM, as every rank would read the same archive), rank 0
 scans it and broadcasts the block/segment table, every rank derives the same
-longest-first plan (multigpu.lpt_assign) and decodes its shard with
+longest-first plan over the estimated block costs (multigpu.lpt_assign over
+zpaqhip_block_costs) and decodes its shard with
 zpaqhip_decode_blocks_device(ids = shard); per-block results are all-gathered
 inside the timed region.  RCCL carries the table and the results only — no
-payload moves during decode (blocks are independent units).
+payload moves during decode (blocks are independent units).  --schedule queue
+replaces the fixed shards by the dynamic work queue (multigpu.WorkQueue: ranks
+pull chunks of --queue-blocks blocks from one counter on the job's store).
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
   N>1:   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
@@ -93,8 +96,15 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra figures of the N=1 line (host_to_host, all-core CPU, configs[2] / [4] shaped runs)")
-    ap.add_argument("--extras-block-bytes", type=int, default=512 << 10,
-                    help="block size of the configs[2] / configs[4] shaped extra runs (256 blocks each; full size = 4194304)")
+    ap.add_argument("--extras-block-bytes", type=int, default=4 << 20,
+                    help="block size of the configs[2] / configs[4] shaped extra runs (256 blocks each; BASELINE size = 4194304)")
+    ap.add_argument("--extras-distinct", type=int, default=64,
+                    help="distinct blocks written for each extra run; the 256 blocks are these, repeated (blocks decode "
+                         "independently, each in its own arena slot, so a repeated block costs what a distinct one costs; "
+                         "writing 1 GiB with the max model takes the host cores minutes)")
+    ap.add_argument("--schedule", default="lpt", help="N > 1: lpt (fixed shards, longest-first over estimated block costs) | "
+                                                      "queue (ranks pull chunks from the shared work queue)")
+    ap.add_argument("--queue-blocks", type=int, default=256, help="--schedule queue: blocks per pull")
     ap.add_argument("--gen-threads", type=int, default=None)
     ap.add_argument("--kernel", type=int, default=0, help="zpaqhip_opts.kernel (0 auto; 5 = round-1 chain kernels for min/mid/max)")
     ap.add_argument("--cache-dir", default=None, help="keep generated streams here and reuse them (profiling runs)")
@@ -132,20 +142,38 @@ def roofline(base_model, kms, plain_bytes, rho, nb, bs, model_tag):
             "issue": issue_bound(base_model, kms, plain_bytes, waves)}
 
 
-# Instructions the decoder wave of a block executes per plaintext byte on its hot path: static counts of the gfx950 ISA
-# (L1: the hand-written loop of zh_cm_fast.h; min / mid / max: zh_decode_c2_* from the EOS flag to the byte boundary's
-# last instruction, cold blocks excluded).  A lone wavefront issues at most one instruction per 4
-# cycles (tools/ubench/salu_bench), which is the ceiling the measured cycles per byte are set against.
-DECODER_INSTR_PER_BYTE = {"l1": 170, "min": 1000, "mid": 1650, "max": 3200}
+# Instructions the decoder wave of a block executes per plaintext byte: static counts of the gfx950 code objects taken by
+# tools/count_instr.py (llvm-objdump -d of libzpaqhip.so; the byte loop from the EOS flag to the loop's backward branch),
+# committed as profiles/<round>/instr_<kernel>.json with the hash of the sources they were counted on.  A count taken on
+# other sources than the ones this run uses is refused, like a stale PMC summary.  A lone wavefront issues at most one
+# instruction per 4 cycles (tools/ubench/salu_bench), which is the ceiling the measured cycles per byte are set against.
+INSTR_KERNEL = {"l1": "zh_decode_cm", "min": "zh_decode_c2_min", "mid": "zh_decode_c2_mid", "max": "zh_decode_c2_max"}
 ISSUE_CYCLES_PER_INSTR = 4
+
+
+def decoder_instr_per_byte(base_model):
+    """(count, source file) or (None, reason)."""
+    sym = INSTR_KERNEL.get(base_model)
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"instr_{sym}.json"))) if sym else []
+    if not cands:
+        return None, "no instruction count committed for this kernel (tools/count_instr.py)"
+    cur = source_hash()
+    for f in reversed(cands):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("src_hash") == cur:
+            return int(d["instr_per_byte_static"]), os.path.relpath(f, ROOT)
+    return None, f"the committed instruction counts were taken on other kernel sources than {cur}"
 
 
 def issue_bound(base_model, kms, plain_bytes, waves):
     cyc = kms * 1e-3 * CLOCK_GHZ * 1e9 / (plain_bytes / waves)
-    n = DECODER_INSTR_PER_BYTE.get(base_model)
+    n, src = decoder_instr_per_byte(base_model)
     return {"blocks_in_flight": waves,
             "cycles_per_plain_byte_per_block": cyc,
-            "decoder_wave_instr_per_plain_byte": n,
+            "decoder_wave_instr_per_plain_byte": n, "instr_source": src,
             "ceiling_cycles_per_instr": ISSUE_CYCLES_PER_INSTR,
             "frac_of_issue_ceiling": (n * ISSUE_CYCLES_PER_INSTR / cyc) if n else None,
             "note": "the operative bound is the dependent instruction chain of the wave that owns a block: the block's speed is "
@@ -154,49 +182,86 @@ def issue_bound(base_model, kms, plain_bytes, waves):
                     "live in LDS, above them where the helper wave speculates over 16 candidate bytes)"}
 
 
-def method_streams(z, synth, ctx, kib=64, blocks=256):
-    """The widened row: streams written with the reference's LZ77 method strings, whose cost is the
-    post-processor (zh_zpaql_pcomp.h).  One block per method, replicated (identical blocks decode independently);
-    host buffer to host buffer, checked against the plaintext."""
-    import time
+def method_streams(z, synth, ctx, kib=4096, blocks=256, threads=None):
+    """The widened row: streams written with the reference's method strings whose whole cost is the
+    post-processor — lazy2 / lzpre (LZ77, LibZPAQ.cs:427-639) and bwtrle (inverse BWT, :642-795) on unmodelled blocks:
+    the wave-wide kernels of zh_store.hip.  256 DISTINCT blocks of 4 MiB, pre-processed by zpaqgen in the LZBuffer.cs:96-115
+    formats; host buffer to host buffer, stored SHA-1 verified on the device, every block compared with its plaintext."""
     from tools import methods
-    plain = synth.plain("T", 7, kib << 10).tobytes()
+    bs = kib << 10
     out = []
-    for mt, what in (("x0,1,4,0,3,16", "lazy2: bit-packed LZ77, no model"), ("x0,2,12,0,7,16", "lzpre: byte-aligned LZ77, no model"),
-                     ("x0,5,4,0,3,16", "lazy2 + E8E9")):
-        s = methods.compress_block(mt, plain) * blocks
-        got = ctx.decompress(s)                                   # warm-up: arena allocation
-        ok = got.size == len(plain) * blocks and got[:len(plain)].tobytes() == plain and got[-len(plain):].tobytes() == plain
+    for mt, what in (("x2,1,4,0,3,22", "lazy2: bit-packed LZ77, no model"), ("x2,2,12,0,7,22", "lzpre: byte-aligned LZ77, no model"),
+                     ("x3,3", "bwtrle: BWT, no model")):
+        model, margs = methods.model_of(mt)
+        s, _ = synth.method_stream(model, margs, "T", blocks, bs, threads=threads)
+        got = ctx.decompress(s, out_cap=bs * blocks, verify_sha1=True)          # warm-up (arena allocation) + check
+        ok = got.size == bs * blocks and all(np.array_equal(got[b * bs:(b + 1) * bs], synth.plain("T", b, bs)) for b in range(blocks))
+        del got
         t0 = time.time()
-        ctx.decompress(s)
+        ctx.decompress(s, out_cap=bs * blocks)
         dt = time.time() - t0
-        out.append({"method": mt, "what": what, "workload": f"{blocks} x {kib} KiB blocks (one block replicated), text-like plaintext",
-                    "value": (len(plain) * blocks / dt / 1e6) if ok else 0.0, "unit": "MB/s (host to host)",
-                    "kernel_ms": float(ctx.stats().kernel_ms), "bit_exact": bool(ok)})
+        kms = float(ctx.stats().kernel_ms)
+        out.append({"method": mt, "what": what, "workload": f"{blocks} x {kib} KiB distinct blocks, text-like plaintext, coded {s.size / 1e6:.0f} MB",
+                    "value": (bs * blocks / dt / 1e6) if ok else 0.0, "unit": "MB/s (host to host)",
+                    "kernel_ms": kms, "kernel_MBps": bs * blocks / (kms * 1e-3) / 1e6 if kms else None, "bit_exact": bool(ok)})
     return out
 
 
-def resident_run(z, synth, torch, ctx, dev, model_name, kind, nb, bs, threads, cache_dir):
-    """One GPU, one decode pass over a resident stream: (MB/s, kernel_ms, rho, bit_exact, stats)."""
+def resident_run(z, synth, torch, ctx, dev, model_name, kind, nb, bs, threads, cache_dir, distinct=None):
+    """One GPU, one decode pass over a resident stream: (MB/s, kernel_ms, rho, bit_exact, stats, stream, scan).  `distinct` < nb: only
+    that many blocks are written and the stream repeats them (see --extras-distinct)."""
     from zpaqsharp_amd import models
-    stream, _ = make_stream(synth, models.get(model_name), model_name, kind, nb, bs, 0, threads, cache_dir)
+    nd = min(nb, distinct or nb)
+    part, _ = make_stream(synth, models.get(model_name), model_name, kind, nd, bs, 0, threads, cache_dir)
+    stream = np.concatenate([part] * (nb // nd) + [part[:0]]) if nd < nb and nb % nd == 0 else part
+    if stream is part and nd < nb:
+        raise SystemExit("--extras-distinct must divide the block count")
     sc = z.scan(stream)
-    d_in = torch.from_numpy(stream).to(dev)
+    assert sc.n_blocks == nb
+    d_in = torch.from_numpy(np.concatenate([stream, np.zeros(16, np.uint8)])).to(dev)
     d_out = torch.zeros(nb * bs, dtype=torch.uint8, device=dev)
     off, cap = [i * bs for i in range(nb)], [bs] * nb
-    for timed in (False, True):               # the first pass allocates the arena (tens of GB for the max model)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        rc, res = ctx.decode_blocks_device(d_in.data_ptr(), stream.size, sc, d_out.data_ptr(), off, cap, h_in=stream)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+    # untimed: as many blocks of 1 KiB with the same model — the call allocates the arena (tens of GB for the max model)
+    # and loads the code object
+    warm, _ = make_stream(synth, models.get(model_name), model_name, kind, nb, 1024, 0, threads, cache_dir)
+    ctx.decompress(warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rc, res = ctx.decode_blocks_device(d_in.data_ptr(), stream.size, sc, d_out.data_ptr(), off, cap, h_in=stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
     st = ctx.stats()
     ok = all(r.status == 0 and r.out_len == bs for r in res)
     if ok:
         got = d_out.cpu().numpy()
-        ok = all(np.array_equal(got[b * bs:(b + 1) * bs], synth.plain(kind, b, bs)) for b in range(nb))
+        ok = all(np.array_equal(got[b * bs:(b + 1) * bs], synth.plain(kind, b % nd, bs)) for b in range(nb))
     rho = sum(s.data_len for s in sc.segments) / (nb * bs)
-    return nb * bs / dt / 1e6, float(st.kernel_ms), rho, ok, st
+    return nb * bs / dt / 1e6, float(st.kernel_ms), rho, ok, st, stream, sc
+
+
+def cpu_all_cores(oracle, h_stream, block_start, n_glob, bs, per, threads):
+    """The C oracle on `threads` host threads, `per` consecutive blocks each (one oracle instance per thread; ctypes
+    releases the GIL): the all-core CPU figure SURVEY.md 8d asks for beside the 1-thread baseline."""
+    pieces = []
+    for i in range(threads):
+        b0 = (i * per) % max(1, n_glob - per + 1)
+        pieces.append(h_stream[block_start[b0]:block_start[b0 + per]].tobytes())
+    done = [0] * threads
+
+    def work(i):
+        done[i] = len(oracle.decompress(pieces[i], cap=per * bs + 16))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    t0 = time.perf_counter()
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dt = time.perf_counter() - t0
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"value": sum(done) / dt / 1e6, "unit": "MB/s", "threads": threads, "host_logical_cores": os.cpu_count(),
+            "cores_this_process_may_use": usable,
+            "sample": f"{threads} threads x {per} block(s) of the same stream ({sum(done) >> 20} MiB plaintext), one oracle instance per thread"}
 
 
 def main():
@@ -234,6 +299,10 @@ def main():
     nb, bs = args.blocks, args.block_bytes
     model = models.get(model_name)
     ncpu = os.cpu_count() or 1
+    try:
+        usable_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable_cores = ncpu
     gen_threads = args.gen_threads or max(1, min(32, ncpu // max(1, min(world, 8))))
 
     # ---- the shared stream: this rank writes global blocks [rank*nb, (rank+1)*nb)
@@ -248,11 +317,20 @@ def main():
     n_glob = job.sc.n_blocks
     assert n_glob == nb * world, (n_glob, nb, world)
     mine = job.shard
-    d_out = torch.zeros(max(1, len(mine)) * bs, dtype=torch.uint8, device=dev)
-    out_off = [i * bs for i in range(len(mine))]
-    out_cap = [bs] * len(mine)
+    dynamic = world > 1 and args.schedule == "queue"
+    if dynamic:
+        # any rank may decode any block: every block has its place (global id x block size) in every rank's buffer
+        d_out = torch.zeros(n_glob * bs, dtype=torch.uint8, device=dev)
+        out_off = [i * bs for i in range(n_glob)]
+        out_cap = [bs] * n_glob
+    else:
+        d_out = torch.zeros(max(1, len(mine)) * bs, dtype=torch.uint8, device=dev)
+        out_off = [i * bs for i in range(len(mine))]
+        out_cap = [bs] * len(mine)
 
     def step():
+        if dynamic:                                          # ranks pull chunks from the shared queue (+ all_gather of the results)
+            return job.decode_dynamic(d_out, out_off, out_cap, queue_blocks=args.queue_blocks, kernel=args.kernel)
         return job.decode(d_out, out_off, out_cap, kernel=args.kernel)         # HIP decode of the shard (+ all_gather of the results)
 
     def barrier():
@@ -267,7 +345,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         table = step()
-        kernel_ms.append(ctx.stats().kernel_ms)
+        kernel_ms.append(job.kernel_ms if dynamic else ctx.stats().kernel_ms)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -280,7 +358,13 @@ def main():
     ok = bool((table[:, 0] == 0).all() and (table[:, 1] == bs).all())
     if not args.no_verify:
         got = d_out.cpu().numpy()
-        for j, b in enumerate(mine):
+        if dynamic:
+            mine = [b for ids in job.pulled for b in ids]    # what this rank decoded in the last pass, at its global place
+            where = {b: b for b in mine}
+        else:
+            where = {b: j for j, b in enumerate(mine)}
+        for b in mine:
+            j = where[b]
             if not np.array_equal(got[j * bs:(j + 1) * bs], synth.plain(kind, b, bs)):
                 ok = False
                 break
@@ -290,6 +374,11 @@ def main():
         allv = multigpu.all_gather_table(np.array([int(ok)], dtype=np.int64), dist, coll_dev)
         ok = bool(allv.all())
     rho = coded_bytes / total_plain
+    rank_kernel_ms = None
+    if world > 1:
+        kk = multigpu.all_gather_table(np.array([int(round(float(np.mean(kernel_ms)) * 1000)), len(mine)], dtype=np.int64), dist, coll_dev)
+        rank_kernel_ms = [float(x) / 1000.0 for x in kk[:, 0]]
+        rank_blocks = [int(x) for x in kk[:, 1]]
 
     if rank != 0:
         if world > 1:
@@ -317,24 +406,8 @@ def main():
                "sample": f"first {S} of {n_glob} blocks ({S * bs >> 20} MiB plaintext) of the same stream, "
                          f"oracle/zpaq_oracle.c -O2, 1 thread, host has {ncpu} logical cores"}
         if world == 1 and not args.no_extras:
-            # all the host cores one GPU's share of the box offers (SURVEY §8d ii): blocks spread over threads
-            T = max(1, min(16, ncpu))
-            per = max(1, S // 4)
-            pieces = []
-            for i in range(T):
-                b0 = (i * per) % max(1, n_glob - per + 1)
-                pieces.append(job.h_stream[block_start[b0]:block_start[b0 + per]].tobytes())
-            done = [0] * T
-
-            def work(i):
-                done[i] = len(oracle.decompress(pieces[i], cap=per * bs + 16))      # ctypes releases the GIL
-            th = [threading.Thread(target=work, args=(i,)) for i in range(T)]
-            t0 = time.perf_counter()
-            [t.start() for t in th]
-            [t.join() for t in th]
-            dt = time.perf_counter() - t0
-            extras["cpu_all_cores"] = {"value": sum(done) / dt / 1e6, "unit": "MB/s", "threads": T,
-                                       "sample": f"{T} threads x {per} block(s) of the same stream, one oracle instance per thread"}
+            # every host core this process may use (SURVEY 8d ii): blocks spread over threads
+            extras["cpu_all_cores"] = cpu_all_cores(oracle, job.h_stream, block_start, n_glob, bs, max(1, S // 8), max(1, min(usable_cores, 64)))
 
     if world == 1 and not args.no_extras:
         # host buffer -> host buffer through zpaqhip_decompress (scan + H2D + kernel + D2H), pinned memory
@@ -348,21 +421,31 @@ def main():
         extras["host_to_host"] = {"value": n / dt / 1e6, "unit": "MB/s", "memory": "pinned",
                                   "fraction_of_resident_rate": (n / dt / 1e6) / value if value else None,
                                   "h2d_ms": s2.h2d_ms, "kernel_ms": s2.kernel_ms, "d2h_ms": s2.d2h_ms, "launches": int(s2.launches),
-                                  "bit_exact": bool(n == total_plain and np.array_equal(h_out.numpy()[-bs:], synth.plain(kind, n_glob - 1, bs)))}
+                                  "bit_exact": bool(n == total_plain and all(
+                                      np.array_equal(h_out.numpy()[b * bs:(b + 1) * bs], synth.plain(kind, b, bs)) for b in range(n_glob)))}
         del h_in, h_out
         # BASELINE configs[2] (mid) and configs[4] (max + the reference's E8E9 PCOMP) shaped runs, 256 blocks each
         if model_name == "l1":
-            ebs = args.extras_block_bytes
+            ebs, nd = args.extras_block_bytes, args.extras_distinct
             for mname, mkind in (("mid", "T"), ("max+e8e9", "X")):
-                v, k, r, okx, sx = resident_run(z, synth, torch, ctx, dev, mname, mkind, 256, ebs, gen_threads, args.cache_dir)
-                extras.setdefault("other_configs", []).append({
+                v, k, r, okx, sx, xs, xsc = resident_run(z, synth, torch, ctx, dev, mname, mkind, 256, ebs, gen_threads, args.cache_dir, nd)
+                rec = {
                     "config": "BASELINE configs[2]" if mname == "mid" else "BASELINE configs[4]",
                     "workload": f"256 x {ebs >> 10} KiB blocks, model {mname}, plaintext {mkind}"
-                                + ("" if ebs == 4 << 20 else " (block size reduced so that the default run stays within minutes; "
-                                   "full-size runs: profiles/)"),
+                                + (f" ({nd} distinct blocks, repeated {256 // nd} x: each block decodes independently in its own arena slot)" if nd < 256 else ""),
                     "value": v if okx else 0.0, "unit": "MB/s", "bit_exact": bool(okx), "kernel_kind": int(sx.kernel_kind),
-                    "roofline": roofline(mname.split("+")[0], k, 256 * ebs, r, 256, ebs, mname)})
-            extras["method_streams"] = method_streams(z, synth, ctx)
+                    "roofline": roofline(mname.split("+")[0], k, 256 * ebs, r, 256, ebs, mname)}
+                if not args.no_cpu_baseline:
+                    xstart = [int(b.tag_off) for b in xsc.blocks] + [int(xs.size)]
+                    t0 = time.perf_counter()
+                    out = oracle.decompress(xs[:xstart[1]].tobytes(), cap=ebs + 16)
+                    dt = time.perf_counter() - t0
+                    rec["cpu_baseline"] = {"value": len(out) / dt / 1e6, "unit": "MB/s", "cores": 1, "kind": "port",
+                                           "sample": f"first block ({ebs >> 20} MiB plaintext) of the same stream, oracle/zpaq_oracle.c -O2, 1 thread"}
+                    rec["cpu_all_cores"] = cpu_all_cores(oracle, xs, xstart, 256, ebs, 1, max(1, min(usable_cores, 32)))
+                del xs
+                extras.setdefault("other_configs", []).append(rec)
+            extras["method_streams"] = method_streams(z, synth, ctx, threads=gen_threads)
 
     line = {
         "metric": "decompress MB/s (bit-exact) on 1 GiB multi-block stream",
@@ -377,10 +460,13 @@ def main():
                         f"model {model_name} ({model.n} component(s)), plaintext generator {kind}",
             "zpaq_model": model_name, "blocks_per_gpu": nb, "block_bytes": bs, "plaintext": kind,
             "coded_over_plain": round(rho, 4),
-            "parallelism": (f"blocks x{world}: shared stream, broadcast table, LPT plan, ids-sharded HIP decode, all_gather of results"
-                            if world > 1 else "blocks x1"),
+            "parallelism": ((f"blocks x{world}: shared stream, broadcast table, work queue (chunks of {args.queue_blocks} cost-ordered blocks, "
+                             f"one counter on the job's store), all_gather of results" if dynamic else
+                             f"blocks x{world}: shared stream, broadcast table, LPT plan over estimated block costs, ids-sharded HIP decode, "
+                             f"all_gather of results") if world > 1 else "blocks x1"),
             "kernel_kind": int(st.kernel_kind), "blocks_in_flight": int(st.concurrent),
-            "shard_blocks": [len(s) for s in job.plan],
+            "shard_blocks": rank_blocks if world > 1 else [len(s) for s in job.plan],
+            "rank_kernel_ms": rank_kernel_ms,
         },
         "roofline": roofline(base, kms, len(mine) * bs, rho, len(mine), bs, model_name),
         "cpu_baseline": cpu,

@@ -125,7 +125,9 @@ typedef struct zpaqhip_opts {
                                  0 = default (1<<32).  Exceeding it ends the block with ZPAQHIP_E_BUDGET */
   uint64_t batch_blocks;      /* whole-stream forms: blocks per pipeline batch; 0 = default (at least 256 blocks and 32 MiB
                                  of coded bytes per batch, so that every CU has a block) */
-  uint64_t reserved[3];
+  uint64_t queue_blocks;      /* zpaqhip_decompress_multi: blocks per pull from the shared work queue; 0 = default (256: one
+                                 block per CU of the device that takes the chunk) */
+  uint64_t reserved[2];
 } zpaqhip_opts;
 
 /* Timing / accounting of the last decode call on a context (the reference's
@@ -193,13 +195,28 @@ int zpaqhip_decompress_cb(zpaqhip_ctx *ctx, zpaqhip_read_fn read_fn, zpaqhip_wri
 /* ---- whole stream on several GPUs of one node (BASELINE.json configs[3]) ----
  * LibZPAQ.decompress(Reader, Writer) (LibZPAQ.cs:65-79) for a caller that owns more than one GPU and no
  * torch.distributed ranks (the C# host): one context and one host thread per entry of `devices` (a device may be
- * listed more than once), blocks dealt longest-first over them (the same plan zpaqsharp_amd/multigpu.py derives per
- * rank), each device decodes its shard, plaintext arrives in `out` in stream order.  With a decimal size in every
- * segment comment (LibZPAQ.compressBlock writes it, LibZPAQ.cs:298-300) every device copies its blocks straight to their
- * final place; otherwise the shards pass through host buffers.  No context is needed or kept. */
+ * listed more than once; the contexts then share its memory budget).  The threads pull chunks of
+ * opts->queue_blocks blocks from ONE work queue ordered by estimated cost (zpaqhip_block_costs), so a device that is
+ * faster takes more chunks; plaintext arrives in `out` in stream order.  With a decimal size in every segment comment
+ * (LibZPAQ.compressBlock writes it, LibZPAQ.cs:298-300) every device copies its blocks straight to their final place;
+ * a block without a plausible size, or with a wrong one, is kept in a host buffer and put in place (it and what
+ * follows it) when all sizes are known — no block is decoded twice.  A damaged block ends the call with its error
+ * after every block before it has been delivered (*out_len = their bytes).  No context is needed or kept.
+ * The _stats form also fills per_device[0..n_devices) (kernel_ms, blocks, ... summed over the chunks a device took;
+ * launches = chunks). */
 int zpaqhip_decompress_multi(const int *devices, size_t n_devices, const uint8_t *in, size_t in_len,
                              uint8_t *out, size_t out_cap, size_t *out_len,
                              const zpaqhip_opts *opts, zpaqhip_err *err);
+int zpaqhip_decompress_multi_stats(const int *devices, size_t n_devices, const uint8_t *in, size_t in_len,
+                                   uint8_t *out, size_t out_cap, size_t *out_len,
+                                   const zpaqhip_opts *opts, zpaqhip_stats *per_device, zpaqhip_err *err);
+
+/* Estimated decode cost of each block of a scanned stream, the weight every multi-GPU plan here uses: plaintext bytes
+ * (the comment's decimal size when plausible, else 4 x coded bytes) x the instructions per plaintext byte of the kernel
+ * the block's header selects.  Decode time of a block is its bit count times the depth of its model
+ * (Predictor.cs:245-475 runs once per bit), not its coded size.  Host-side, no GPU needed. */
+int zpaqhip_block_costs(const uint8_t *in, size_t in_len, const zpaqhip_block *blocks, size_t n_blocks,
+                        const zpaqhip_segment *segs, size_t n_segs, uint64_t *cost, zpaqhip_err *err);
 
 /* ---- explicit block-table form, device-resident buffers ------------------
  * Replaces the per-block inner loop Decompresser.decompress(-1)

@@ -309,28 +309,31 @@ def test_three_wave_kernels_match_the_oracle(ctx, model, kernel):
     assert e1.value.code == e0.value.code
 
 
-def test_two_ranks_on_one_gpu_run_the_sharded_hip_decode(tmp_path):
-    """bench.py's N > 1 path — shared stream, broadcast table, LPT plan, zpaqhip_decode_blocks_device(ids = shard),
-    all_gather of the results — rehearsed with two gloo ranks that share this box's one GPU."""
+@pytest.mark.parametrize("schedule", ["lpt", "queue"])
+def test_two_ranks_on_one_gpu_run_the_sharded_hip_decode(tmp_path, schedule):
+    """bench.py's N > 1 path — shared stream, broadcast table, plan over the estimated block costs (or, `queue`, chunks
+    pulled from the counter on the job's store), zpaqhip_decode_blocks_device(ids), all_gather of the results — rehearsed
+    with two gloo ranks that share this box's one GPU."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577" if schedule == "lpt" else "29579", WORLD_SIZE="2")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--share-gpu", "--model", "mid",
-           "--blocks", "5", "--block-bytes", "40000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--gen-threads", "2"]
+           "--blocks", "5", "--block-bytes", "40000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--gen-threads", "2",
+           "--schedule", schedule, "--queue-blocks", "2"]
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
              for r in range(2)]
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1].decode()[-2000:] for o in outs]
     line = json.loads(outs[0][0].decode().strip().splitlines()[-1])
     assert line["bit_exact"] is True and line["n_gpus"] == 2 and line["value"] > 0
-    assert sorted(line["config"]["shard_blocks"]) == [5, 5] and line["config"]["kernel_kind"] == 3
+    assert sum(line["config"]["shard_blocks"]) == 10 and line["config"]["kernel_kind"] == 3
+    if schedule == "lpt":
+        assert sorted(line["config"]["shard_blocks"]) == [5, 5]
+    assert len(line["config"]["rank_kernel_ms"]) == 2 and max(line["config"]["rank_kernel_ms"]) > 0
 
 
-# ---------------------------------------------------------------------------------------
-# whole-stream pipeline (batches, Reader/Writer streaming, unknown sizes, damage behind good blocks)
-# ---------------------------------------------------------------------------------------
 def _mixed_stream(n_blocks=23, seed=5):
     rng = np.random.default_rng(seed)
     parts, plain = [], []
@@ -448,18 +451,69 @@ def test_good_blocks_before_damage_are_delivered(ctx):
 
 
 def test_multi_device_entry_point_with_contexts_sharing_this_gpu(ctx):
-    """zpaqhip_decompress_multi (the C# host's way to use several GPUs): N contexts on N host threads, LPT plan, output
-    in stream order.  This box has one GPU, so the device list repeats it; sizes from the comments (direct placement),
-    missing / wrong sizes (shards through host buffers), framing damage behind good blocks."""
+    """zpaqhip_decompress_multi (the C# host's way to use several GPUs): N contexts on N host threads pulling chunks
+    from one cost-ordered queue, output in stream order.  This box has one GPU, so the device list repeats it.  Sizes
+    from the comments (direct placement); missing / wrong sizes (that block is held back and put in place, nothing is
+    decoded twice); damage behind good blocks (they are delivered, then the damaged block's error)."""
     s, want = _mixed_stream(n_blocks=19, seed=3)                 # some comments carry no or a bogus size
-    for devs in ([0], [0, 0], [0, 0, 0]):
-        assert z.decompress_multi(devs, s, verify_sha1=True).tobytes() == want, devs
+    for devs, qb in (([0], 0), ([0, 0], 4), ([0, 0, 0], 3), ([0, 0], 1)):
+        per = []
+        assert z.decompress_multi(devs, s, verify_sha1=True, queue_blocks=qb, per_device=per).tobytes() == want, devs
+        assert sum(int(p_.blocks) for p_ in per) == 19 and len(per) == len(devs)        # every block decoded once
+        assert sum(int(p_.launches) for p_ in per) == (1 if qb == 0 else -(-19 // qb))   # chunks taken
+        assert sum(int(p_.out_bytes) for p_ in per) == len(want)
     parts = [util.text(20000 + 3000 * i, seed=50 + i) for i in range(9)]
     s2 = b"".join(util.block(("l1", "mid", "min")[i % 3], d) for i, d in enumerate(parts))   # every block sized: placed path
-    assert z.decompress_multi([0, 0], s2, verify_sha1=True).tobytes() == b"".join(parts)
-    wrong = util.block("l1", parts[0], comment=b"5") + util.block("mid", parts[1])           # a wrong size: falls back
-    assert z.decompress_multi([0, 0], wrong, verify_sha1=True).tobytes() == parts[0] + parts[1]
-    bad = bytearray(util.block("l1", parts[2]))
-    bad[z.scan(bytes(bad)).segments[0].data_off + 30] ^= 4
+    assert z.decompress_multi([0, 0], s2, verify_sha1=True, queue_blocks=2).tobytes() == b"".join(parts)
+    # wrong sizes, too small and too large, between sized blocks: only those blocks are re-placed
+    blocks = [util.block("l1", parts[0]), util.block("l1", parts[1], comment=b"5"), util.block("mid", parts[2]),
+              util.block("min", parts[3], comment=b"900000"), util.block("l1", parts[4]), util.block("mid", parts[5], comment=b"x"),
+              util.block("l1", parts[6], comment=str(len(parts[6]) + 1).encode()), util.block("l1", parts[7])]
+    wrong = b"".join(blocks)
+    for qb in (1, 3, 0):
+        per = []
+        got = z.decompress_multi([0, 0], wrong, verify_sha1=True, queue_blocks=qb, per_device=per).tobytes()
+        assert got == b"".join(parts[:8]), qb
+        assert sum(int(p_.blocks) for p_ in per) == 8
+    assert z.decompress_multi([0, 0], wrong, out_cap=len(b"".join(parts[:8])), queue_blocks=2).tobytes() == b"".join(parts[:8])
+    # damage in block 5 of 9: blocks 0-4 arrive, the error is the one a single context reports
+    cut = z.scan(s2).blocks
+    bad = bytearray(s2)
+    bad[z.scan(s2).segments[cut[5].first_seg].data_off + 30] ^= 4
+    with pytest.raises(z.ZpaqError) as e1:
+        ctx.decompress(bytes(bad))
+    for qb in (2, 0):
+        got, e2 = z.decompress_multi([0, 0], bytes(bad), queue_blocks=qb, partial=True)
+        assert e2 is not None and e2.code == e1.value.code and e2.block == 5
+        assert got.tobytes() == b"".join(parts[:5])
     with pytest.raises(z.ZpaqError):
-        z.decompress_multi([0, 0], s2 + bytes(bad))
+        z.decompress_multi([0, 0], bytes(bad))
+
+
+def test_multi_device_queue_balances_an_archive_that_mixes_models(ctx):
+    """An archive of l1 / mid / max blocks of uneven sizes, two contexts on this GPU pulling from the cost-ordered queue:
+    bit-exact, and the kernel time of the two device threads ends within 10 % of each other.  (By coded bytes — the
+    round-2 weight — an l1 block outweighs a max block of the same plaintext although it decodes 18 x faster.)"""
+    rng = np.random.default_rng(12)
+    parts, blocks = [], []
+    for i in range(120):
+        model = ("l1", "mid", "max")[i % 3]
+        d = util.text(int(rng.integers(8000, 40000)), seed=300 + i)
+        parts.append(d)
+        blocks.append(synth.compress_block(model, np.frombuffer(d, np.uint8)))
+    s = b"".join(blocks)
+    want = b"".join(parts)
+    sc = z.scan(s)
+    costs = z.block_costs(s, sc)
+    coded = np.array([int(sc.segments[b.first_seg].data_len) for b in sc.blocks])
+    assert costs[2] > 10 * costs[0] * (len(parts[2]) / len(parts[0])) * 0.9 and coded[0] > 0
+    z.decompress_multi([0, 0], s, queue_blocks=4)                 # warm-up: arenas, code objects
+    best = 1.0
+    for _ in range(3):
+        per = []
+        got = z.decompress_multi([0, 0], s, verify_sha1=True, queue_blocks=4, per_device=per).tobytes()
+        assert got == want
+        k = [float(p_.kernel_ms) for p_ in per]
+        assert sum(int(p_.blocks) for p_ in per) == 120 and sum(int(p_.launches) for p_ in per) == 30
+        best = min(best, abs(k[0] - k[1]) / max(k))
+    assert best < 0.10, best

@@ -54,6 +54,48 @@ def test_lpt_assignment_is_balanced_and_deterministic():
     assert multigpu.interleave_assign(7, 3) == [[0, 3, 6], [1, 4], [2, 5]]
 
 
+def test_queue_chunks_are_cross_sections_and_the_queue_hands_every_block_out_once():
+    import random
+    import threading
+    rnd = random.Random(4)
+    costs = [rnd.choice((170, 1600, 3100)) * rnd.randint(1000, 5000) for _ in range(1000)]
+    chunks = multigpu.queue_chunks(costs, 256)
+    assert len(chunks) == 4 and sorted(sum(chunks, [])) == list(range(1000)) and all(c == sorted(c) for c in chunks)
+    tot = [sum(costs[i] for i in c) for c in chunks]
+    assert max(tot) - min(tot) <= max(costs)                 # chunk totals differ by less than one block
+    assert multigpu.queue_chunks([], 256) == [] and multigpu.queue_chunks([5], 256) == [[0]]
+    # many pullers, one counter: every chunk goes to exactly one of them
+    q = multigpu.WorkQueue(costs, multigpu.LocalCounter(), 10)
+    got = [[] for _ in range(8)]
+
+    def pull(i):
+        while (c := q.pull()) is not None:
+            got[i].append(c)
+    th = [threading.Thread(target=pull, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert sorted(b for g in got for c in g for b in c) == list(range(1000))
+    assert sum(len(g) for g in got) == 100
+
+
+def test_block_costs_weigh_plaintext_size_and_model_depth():
+    import zpaqsharp_amd as z
+    from tests import util
+    d = util.text(30000, seed=3)
+    s = (util.block("l1", d) + util.block("mid", d) + util.block("max", d) + util.block("mid", d[:10000])
+         + util.block("mid", d, comment=b"no size here"))
+    sc = z.scan(s)
+    c = [int(x) for x in z.block_costs(s, sc)]
+    assert c[0] < c[1] < c[2]                                # same plaintext: deeper model, higher cost
+    assert c[1] == 3 * c[3]                                  # same model: cost follows the plaintext size
+    assert c[0] == 30000 * 170 and c[1] == 30000 * 1600 and c[2] == 30000 * 3100
+    coded = int(sc.segments[sc.blocks[4].first_seg].data_len)
+    assert c[4] == 4 * coded * 1600                          # no size in the comment: 4 x coded bytes
+    plan = multigpu.lpt_assign(c, 2)
+    loads = [sum(c[i] for i in sh) for sh in plan]
+    assert max(loads) <= 0.6 * sum(c)                        # (by coded bytes alone the max block would be paired with mid)
+
+
 _WORKER = r'''
 import hashlib, os, sys
 import numpy as np
@@ -86,11 +128,21 @@ part = stream[:cut] if rank == 0 else stream[cut:]
 job = multigpu.ShardedJob.from_parts(None, part, dist, None)
 assert job.stream_len == stream.size and np.array_equal(job.h_stream, stream)
 assert job.sc.n_blocks == 7 and [int(b.tag_off) for b in job.sc.blocks] == [int(b.tag_off) for b in sc.blocks]
-assert job.plan == multigpu.lpt_assign(weights, 2) and job.shard == job.plan[rank]
+costs = [int(x) for x in z.block_costs(stream, sc)]
+assert costs == [3000 * 170] * 7
+assert job.plan == multigpu.lpt_assign(costs, 2) and job.shard == job.plan[rank]
 def fake(ids):        # CPU stand-in for the HIP decode of a shard
     return [[0, len(oracle.decompress(stream[int(offs[b]):int(offs[b + 1])].tobytes()))] for b in ids]
 t2 = job.decode(None, None, None, decode_fn=fake)
 assert t2.shape == (7, 2) and list(t2[:, 0]) == [0] * 7 and list(t2[:, 1]) == [3000] * 7
+# the dynamic form: both ranks pull chunks of 2 blocks from the queue behind the job's store
+for _ in range(2):                                          # (a second pass uses a fresh counter key)
+    t3 = job.decode_dynamic(None, None, None, queue_blocks=2, decode_fn=fake)
+    assert t3.shape == (7, 3) and list(t3[:, 0]) == [0] * 7 and list(t3[:, 1]) == [3000] * 7
+    took = multigpu.all_gather_table(np.array([len(job.pulled)]), dist).reshape(-1)
+    assert int(took.sum()) == 4 and set(t3[:, 2]) <= {0, 1}
+    for ids in job.pulled:
+        assert all(int(t3[b, 2]) == rank for b in ids)
 dist.destroy_process_group()
 print("rank ok")
 '''

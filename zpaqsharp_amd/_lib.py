@@ -42,7 +42,7 @@ class SegResult(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("verify_sha1", C.c_uint32), ("max_concurrent", C.c_uint32),
                 ("kernel", C.c_uint32), ("zpaql_budget", C.c_uint64), ("batch_blocks", C.c_uint64),
-                ("reserved", C.c_uint64 * 3)]
+                ("queue_blocks", C.c_uint64), ("reserved", C.c_uint64 * 2)]
 
 
 class Stats(C.Structure):
@@ -59,7 +59,7 @@ WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_int)
 SYMBOLS = ("zpaqhip_version", "zpaqhip_strerror", "zpaqhip_device_count", "zpaqhip_ctx_create",
            "zpaqhip_ctx_destroy", "zpaqhip_last_stats", "zpaqhip_scan", "zpaqhip_decompress",
            "zpaqhip_decompress_segments", "zpaqhip_decompress_cb", "zpaqhip_decode_blocks_device", "zpaqhip_read_device_tables",
-           "zpaqhip_block_pcomp", "zpaqhip_decompress_multi")
+           "zpaqhip_block_pcomp", "zpaqhip_decompress_multi", "zpaqhip_decompress_multi_stats", "zpaqhip_block_costs")
 
 _lib = None
 
@@ -100,5 +100,8 @@ def load():
     L.zpaqhip_read_device_tables.argtypes = [vp, vp, vp, vp, vp, vp, errp]
     L.zpaqhip_block_pcomp.argtypes = [vp, vp, sz, C.c_uint32, vp, sz, C.POINTER(sz), errp]
     L.zpaqhip_decompress_multi.argtypes = [C.POINTER(C.c_int), sz, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(Opts), errp]
+    L.zpaqhip_decompress_multi_stats.argtypes = [C.POINTER(C.c_int), sz, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(Opts),
+                                                 C.POINTER(Stats), errp]
+    L.zpaqhip_block_costs.argtypes = [vp, sz, C.POINTER(Block), sz, C.POINTER(Segment), sz, vp, errp]
     _lib = L
     return L

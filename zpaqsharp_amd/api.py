@@ -83,30 +83,56 @@ def scan(stream, partial: bool = False):
     return res
 
 
-def decompress_multi(devices: Sequence[int], stream, out_cap: Optional[int] = None, **opt) -> np.ndarray:
-    """zpaqhip_decompress_multi: LibZPAQ.decompress over several GPUs of one node (one context + host thread per
-    entry of `devices`; an entry may repeat), blocks dealt longest-first, plaintext in stream order."""
+def block_costs(stream, sc: "ScanResult") -> np.ndarray:
+    """zpaqhip_block_costs: estimated decode cost per block (plaintext bytes x instructions per byte of the block's
+    kernel), the weight of every multi-GPU plan (multigpu.py, zpaqhip_decompress_multi).  Host-side."""
+    L = _lib.load()
+    a = _as_u8(stream)
+    cost = np.zeros(max(1, sc.n_blocks), np.uint64)
+    err = Err()
+    rc = L.zpaqhip_block_costs(a.ctypes.data, a.size, sc.blocks, sc.n_blocks, sc.segments, sc.n_segments, cost.ctypes.data, C.byref(err))
+    if rc:
+        _raise(err, rc)
+    return cost[:sc.n_blocks]
+
+
+def decompress_multi(devices: Sequence[int], stream, out_cap: Optional[int] = None, per_device: Optional[list] = None,
+                     partial: bool = False, **opt):
+    """zpaqhip_decompress_multi(_stats): LibZPAQ.decompress over several GPUs of one node (one context + host thread
+    per entry of `devices`; an entry may repeat), the threads pulling chunks of `queue_blocks` blocks from one
+    cost-ordered work queue; plaintext in stream order.  per_device: a list that receives one Stats per device.
+    partial=True: a damaged block does not raise; returns (plaintext before it, ZpaqError | None)."""
     L = _lib.load()
     a = _as_u8(stream)
     o = make_opts(**opt)
     err, n = Err(), C.c_size_t(0)
     devs = (C.c_int * len(devices))(*devices)
     if out_cap is None:
-        hints = [b.usize_hint for b in scan(a, partial=True)[0].blocks]
-        out_cap = sum(h for h in hints if h != UINT64_MAX) if hints and all(h != UINT64_MAX for h in hints) else 0
-    out = np.empty(max(1, out_cap), np.uint8)
-    rc = L.zpaqhip_decompress_multi(devs, len(devices), a.ctypes.data, a.size, out.ctypes.data, out_cap, C.byref(n), C.byref(o), C.byref(err))
-    if rc == -20 and n.value > out_cap:
-        out_cap = n.value
+        sc = scan(a, partial=True)[0]
+        out_cap = 0
+        for b in sc.blocks:
+            coded = sum(int(sc.segments[b.first_seg + i].data_len) for i in range(b.n_seg))
+            out_cap += int(b.usize_hint) if b.usize_hint != UINT64_MAX and b.usize_hint <= 1 << 40 else 8 * coded + (64 << 10)
+    st = (Stats * len(devices))()
+    for _ in range(2):
         out = np.empty(max(1, out_cap), np.uint8)
-        rc = L.zpaqhip_decompress_multi(devs, len(devices), a.ctypes.data, a.size, out.ctypes.data, out_cap, C.byref(n), C.byref(o), C.byref(err))
+        rc = L.zpaqhip_decompress_multi_stats(devs, len(devices), a.ctypes.data, a.size, out.ctypes.data, out_cap, C.byref(n),
+                                              C.byref(o), st, C.byref(err))
+        if not (rc == -20 and n.value > out_cap):
+            break
+        out_cap = n.value
+    if per_device is not None:
+        per_device[:] = [Stats.from_buffer_copy(bytes(x)) for x in st]
+    if partial:
+        e = ZpaqError(rc, err.block, err.segment, err.msg.decode(errors="replace")) if rc else None
+        return out[:min(n.value, out_cap)], e
     if rc:
         _raise(err, rc)
     return out[:n.value]
 
 
 def make_opts(verify_sha1: bool = False, max_concurrent: int = 0, kernel: int = 0, zpaql_budget: int = 0,
-              batch_blocks: int = 0) -> Opts:
+              batch_blocks: int = 0, queue_blocks: int = 0) -> Opts:
     o = Opts()
     o.struct_size = C.sizeof(Opts)
     o.verify_sha1 = int(verify_sha1)
@@ -114,6 +140,7 @@ def make_opts(verify_sha1: bool = False, max_concurrent: int = 0, kernel: int = 
     o.kernel = kernel
     o.zpaql_budget = zpaql_budget
     o.batch_blocks = batch_blocks
+    o.queue_blocks = queue_blocks
     return o
 
 

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <numeric>
@@ -65,6 +66,7 @@ struct zpaqhip_ctx {
   DevBuf in2[2], out2[2], out_fix[2];
   uint8_t *pin[2] = {nullptr, nullptr};
   zpaqhip_stats stats{};
+  uint32_t mem_share = 1;                 // contexts of this process that share the device (zpaqhip_decompress_multi): divides the memory budgets
   std::vector<uint32_t> raw_pp;           // last decode: per segment pp_state | PCOMP length << 8, as the kernels report it
 };
 
@@ -303,7 +305,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
   auto family = [&](size_t k) -> uint32_t {
     uint32_t f = models[bd[k].model].kind & 255u;
     if (opts.kernel == 1) f = ZH_FAM_GENERIC;              // force the generic kernel
-    if (f == ZH_FAM_STORE && (opts.reserved[1] == kPpOnlyMagic)) f = ZH_FAM_GENERIC;
+    if (f == ZH_FAM_STORE && (opts.reserved[0] == kPpOnlyMagic)) f = ZH_FAM_GENERIC;
     if (opts.kernel == 3 && f == ZH_FAM_CM1) f = ZH_FAM_CHAIN;   // force the lane-per-component kernel
     if (opts.kernel == 4 && f > ZH_FAM_CHAIN) f = ZH_FAM_CHAIN;  // lane-per-component kernel without model specialisation
     return f;
@@ -314,7 +316,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
   free_b += c->arena.cap;                               // our own cached arena is reusable
-  const uint64_t mem_budget = free_b > (1ull << 30) ? free_b - (1ull << 30) : free_b / 2;
+  const uint64_t mem_budget = (free_b > (1ull << 30) ? free_b - (1ull << 30) : free_b / 2) / std::max(1u, c->mem_share);
 
   HIPCHK(c->models.reserve(models.size() * sizeof(ZhModel)));
   HIPCHK(c->code.reserve(code.size() + 16));
@@ -375,7 +377,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     L.queue = (uint32_t *)c->queue.p + 8 * g;           // one work-queue head per launch
     L.n_blocks = (uint32_t)groups[g].size();
     L.budget = opts.zpaql_budget;
-    L.flags = opts.reserved[1] == kPpOnlyMagic ? ZH_LAUNCH_PP_ONLY : 0u;
+    L.flags = opts.reserved[0] == kPpOnlyMagic ? ZH_LAUNCH_PP_ONLY : 0u;
     const bool prof = getenv("ZPAQHIP_PROF") != nullptr;   // diagnostic build with in-kernel stamps
     if (prof) L.debug = (uint64_t *)((uint8_t *)c->queue.p + kQueueBytes);
     if (g == ZH_FAM_STORE) {
@@ -570,6 +572,10 @@ struct Sinkk {
   // it really produced
   const uint64_t *place = nullptr;
   std::vector<uint64_t> *sizes = nullptr;
+  // ... and at most place_cap[k] bytes of it; a block that is larger (a wrong or missing size in its comment) is kept
+  // whole in spill[k] and put in place by the caller once every size is known
+  const uint64_t *place_cap = nullptr;
+  std::vector<std::vector<uint8_t>> *spill = nullptr;
 };
 
 constexpr size_t kBatchMinBlocks = 256, kBatchMinBytes = 32u << 20, kBatchMaxBlocks = 4096;
@@ -669,7 +675,7 @@ int plan_staging(zpaqhip_ctx *c, Batch &bt, zpaqhip_err *err) {
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
   free_b += c->out2[0].cap + c->out2[1].cap;
-  const uint64_t budget = free_b / 4;                   // per staging buffer; the arena needs the rest
+  const uint64_t budget = free_b / 4 / std::max(1u, c->mem_share);   // per staging buffer; the arena needs the rest
   uint64_t sum = 0;
   for (size_t b = 0; b < nb; ++b) {
     const zpaqhip_block &B = bt.so.blocks[b];
@@ -814,7 +820,13 @@ int drain_batch(zpaqhip_ctx *c, const Batch &bt, size_t upto_blocks, uint64_t pa
     for (size_t b = 0; b < upto_blocks && b < bt.so.blocks.size(); ++b) {
       const uint64_t n = bt.real[b], at = sink.place[bt.blk0 + b];
       if (sink.sizes) (*sink.sizes)[bt.blk0 + b] = n;
-      if (n && at < sink.cap)
+      if (sink.place_cap && n > sink.place_cap[bt.blk0 + b]) {
+        if (sink.spill) {
+          std::vector<uint8_t> &sp = (*sink.spill)[bt.blk0 + b];
+          sp.resize((size_t)n);
+          HIPCHK(hipMemcpyAsync(sp.data(), block_dev_ptr(c, bt, b), (size_t)n, hipMemcpyDeviceToHost, c->s_out));
+        }
+      } else if (n && at < sink.cap)
         HIPCHK(hipMemcpyAsync(sink.mem + at, block_dev_ptr(c, bt, b), (size_t)std::min<uint64_t>(n, sink.cap - at), hipMemcpyDeviceToHost, c->s_out));
       sink.total += n;
     }
@@ -1054,131 +1066,177 @@ int zpaqhip_decompress(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint8_t
   return ZPAQHIP_OK;
 }
 
-// Several GPUs of one node: one context and one host thread per entry of `devices`; blocks dealt longest-first.
-int zpaqhip_decompress_multi(const int *devices, size_t n_dev, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
-                             size_t *out_len, const zpaqhip_opts *opts_in, zpaqhip_err *err) {
+// Estimated decode cost of every block: plaintext bytes (the decimal size in the comments when it is plausible, else
+// 4 x the coded bytes) x the decoder wavefront's instructions per plaintext byte of the kernel the block's header selects
+// (static ISA counts, tools/count_instr.py; a block's decode time is its bit count x the depth of its model, not its
+// coded size).  Host-side only.
+int zpaqhip_block_costs(const uint8_t *in, size_t in_len, const zpaqhip_block *blocks, size_t n_blocks,
+                        const zpaqhip_segment *segs, size_t n_segs, uint64_t *cost, zpaqhip_err *err) {
+  if ((!in && in_len) || (!blocks && n_blocks) || (!segs && n_segs) || (!cost && n_blocks)) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
+  std::map<std::string, uint64_t> per_byte;
+  for (size_t b = 0; b < n_blocks; ++b) {
+    const zpaqhip_block &B = blocks[b];
+    if (B.hdr_off + B.hdr_len > in_len || (uint64_t)B.first_seg + B.n_seg > n_segs) {
+      set_err(err, ZPAQHIP_E_ARG, (int)b, -1, "block table does not match the stream");
+      return ZPAQHIP_E_ARG;
+    }
+    std::string key((const char *)in + B.hdr_off, B.hdr_len);
+    auto it = per_byte.find(key);
+    if (it == per_byte.end()) {
+      ZhModel m;
+      std::vector<uint8_t> code;
+      zpaqhip_err e2{};
+      uint64_t w = 1000;                                  // a header the model builder refuses costs nothing real; keep it finite
+      if (build_model(in + B.hdr_off, B.hdr_len, m, code, &e2) == ZPAQHIP_OK) {
+        const uint32_t fam = m.kind & 255u;
+        const bool pcomp = (m.ph | m.pm) != 0;
+        w = fam == ZH_FAM_STORE ? (pcomp ? 40u : 4u)                  // zh_store.hip: wave-wide copy / LZ77 / inverse BWT
+            : fam == ZH_FAM_CM1 ? 170u                               // zh_cm_fast.h
+            : fam == ZH_FAM_CHAIN + 1 ? 1000u : fam == ZH_FAM_CHAIN + 2 ? 1600u : fam == ZH_FAM_CHAIN + 3 ? 3100u   // zh_chain2.hip min / mid / max
+            : fam == ZH_FAM_CHAIN ? 600u + 350u * m.n                 // zh_chain.hip: level walk at run time
+            : 1500u + 2500u * m.n;                                    // zh_generic.hip: one lane, tables in HBM
+        if (pcomp && fam != ZH_FAM_STORE) w += 300;
+      }
+      it = per_byte.emplace(key, w).first;
+    }
+    uint64_t coded = 0;
+    for (uint32_t i = 0; i < B.n_seg; ++i) coded += segs[B.first_seg + i].data_len;
+    const uint64_t plain = (B.usize_hint != UINT64_MAX && B.usize_hint <= (1ull << 40)) ? B.usize_hint : coded * 4;
+    cost[b] = std::max<uint64_t>(1, plain) * it->second;
+  }
+  return ZPAQHIP_OK;
+}
+
+// Several GPUs of one node: one context and one host thread per entry of `devices`, all pulling from ONE work queue.
+//   queue   the blocks sorted by estimated cost (zpaqhip_block_costs) are dealt into K = ceil(n / queue_blocks) chunks,
+//           chunk k = every K-th block of that order starting at k (each chunk is a cross-section of the cost
+//           distribution and fills a GPU: queue_blocks defaults to 256, one block per CU); a device thread takes the
+//           next chunk (one atomic counter) whenever it has finished one, so a GPU that is faster, or whose chunks
+//           turned out cheaper than estimated, simply takes more of them
+//   placing block b goes to out + (sum of the plausible comment sizes before it); a block whose comment carries no
+//           plausible size, or the wrong one, is kept whole in a host buffer by the thread that decoded it and only
+//           THAT block (and the blocks behind it, by memmove) is put in place when all sizes are known — nothing is
+//           decoded twice
+//   errors  a damaged block ends its chunk there; the other chunks go on, so that every block before the first damaged
+//           one of the stream is delivered, *out_len says how many bytes that is, and the call returns that block's error
+int zpaqhip_decompress_multi_stats(const int *devices, size_t n_dev, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                                   size_t *out_len, const zpaqhip_opts *opts_in, zpaqhip_stats *per_device, zpaqhip_err *err) {
   if (!devices || !n_dev || (!in && in_len) || !out_len || (!out && out_cap)) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
-  const zpaqhip_opts opts = resolve_opts(opts_in);
+  zpaqhip_opts opts = resolve_opts(opts_in);
+  const size_t chunk_blocks = opts.queue_blocks ? (size_t)opts.queue_blocks : 256;
   *out_len = 0;
+  if (per_device) memset(per_device, 0, n_dev * sizeof(zpaqhip_stats));
   ScanOut so;
   zpaqhip_err scan_err{};
   const int scan_rc = scan_stream(in ? in : (const uint8_t *)"", in_len, so, &scan_err);   // blocks before damage are decoded
   const size_t nb = so.blocks.size();
-  // ---- the plan: longest processing time first, ties by block index (== multigpu.lpt_assign)
-  std::vector<uint64_t> weight(nb, 0);
-  for (size_t b = 0; b < nb; ++b)
-    for (uint32_t i = 0; i < so.blocks[b].n_seg; ++i) weight[b] += so.segs[so.blocks[b].first_seg + i].data_len;
+  if (!nb) { if (scan_rc && err) *err = scan_err; return scan_rc; }
+  // ---- the queue
+  std::vector<uint64_t> cost(nb, 0);
+  { int rc = zpaqhip_block_costs(in, in_len, so.blocks.data(), nb, so.segs.data(), so.segs.size(), cost.data(), err); if (rc) return rc; }
   std::vector<size_t> order(nb);
   std::iota(order.begin(), order.end(), (size_t)0);
-  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight[a] > weight[b]; });
-  std::vector<std::vector<size_t>> shard(n_dev);
-  std::vector<uint64_t> load(n_dev, 0);
-  for (size_t b : order) {
-    size_t r = 0;
-    for (size_t k = 1; k < n_dev; ++k) if (load[k] < load[r]) r = k;
-    shard[r].push_back(b); load[r] += weight[b];
-  }
-  for (auto &sh : shard) std::sort(sh.begin(), sh.end());
-  // ---- placement: with a plausible size in every comment the final offsets are known up front and every device copies
-  // its blocks straight to their place; otherwise (or when a size turns out wrong) shards go through host buffers
-  bool hinted = true;
-  std::vector<uint64_t> final_off(nb + 1, 0);
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+  const size_t K = (nb + chunk_blocks - 1) / chunk_blocks;
+  std::atomic<size_t> next_chunk{0};
+  std::atomic<bool> abort_all{false};
+  // ---- placing
+  std::vector<uint64_t> slot_off(nb + 1, 0), slot_cap(nb, 0), real(nb, 0);
   for (size_t b = 0; b < nb; ++b) {
     const uint64_t h = so.blocks[b].usize_hint;
-    if (h == UINT64_MAX || h > (1ull << 40)) hinted = false;
-    final_off[b + 1] = final_off[b] + (hinted ? h : 0);
+    const bool plausible = h != UINT64_MAX && h <= (1ull << 40) && slot_off[b] + h <= out_cap;
+    slot_cap[b] = plausible ? h : 0;
+    slot_off[b + 1] = slot_off[b] + slot_cap[b];
   }
-  struct Job { int rc = 0; zpaqhip_err err{}; std::vector<uint64_t> sizes; std::vector<uint8_t> sub, tmp; std::vector<uint64_t> place; uint64_t total = 0; };
+  std::vector<std::vector<uint8_t>> spill(nb);
+  std::vector<uint8_t> done(nb, 0);
+  struct Job { int rc = 0; zpaqhip_err err{}; long bad = -1; zpaqhip_stats st{}; };
   std::vector<Job> jobs(n_dev);
-  auto run = [&](size_t r, bool placed) {
+  auto worker = [&](size_t r) {
     Job &J = jobs[r];
-    J.rc = 0; J.total = 0;
-    J.sizes.assign(shard[r].size(), 0);
-    if (shard[r].empty()) return;
-    if (J.sub.empty())
-      for (size_t b : shard[r]) J.sub.insert(J.sub.end(), in + so.blocks[b].tag_off, in + so.blocks[b].end_off);
     zpaqhip_ctx *c = nullptr;
     J.rc = zpaqhip_ctx_create(devices[r], &c, &J.err);
-    if (J.rc) return;
-    Source src; src.mem = J.sub.data(); src.mem_len = J.sub.size();
-    Sinkk sink;
-    if (placed) {
-      J.place.clear();
-      for (size_t b : shard[r]) J.place.push_back(final_off[b]);
-      sink.mem = out; sink.cap = out_cap; sink.place = J.place.data(); sink.sizes = &J.sizes;
-    } else {
-      uint64_t guess = 0;
-      for (size_t b : shard[r]) guess += weight[b] * 4 + 65536;
-      J.tmp.resize((size_t)guess);
-      sink.mem = J.tmp.data(); sink.cap = J.tmp.size();
+    if (J.rc) { abort_all = true; return; }
+    for (size_t k = 0; k < n_dev; ++k) c->mem_share += k != r && devices[k] == devices[r];
+    std::vector<uint8_t> sub;
+    std::vector<size_t> ids;
+    std::vector<uint64_t> place, cap, sizes;
+    std::vector<std::vector<uint8_t>> sp;
+    while (!abort_all) {
+      const size_t k = next_chunk.fetch_add(1);
+      if (k >= K) break;
+      ids.clear();
+      for (size_t i = k; i < nb; i += K) ids.push_back(order[i]);
+      std::sort(ids.begin(), ids.end());                 // stream order inside the chunk: the pipeline delivers in order
+      sub.clear(); place.clear(); cap.clear();
+      for (size_t b : ids) {
+        sub.insert(sub.end(), in + so.blocks[b].tag_off, in + so.blocks[b].end_off);
+        place.push_back(slot_off[b]); cap.push_back(slot_cap[b]);
+      }
+      sizes.assign(ids.size(), 0);
+      sp.assign(ids.size(), std::vector<uint8_t>());
+      Source src; src.mem = sub.data(); src.mem_len = sub.size();
+      Sinkk sink;
+      sink.mem = out; sink.cap = out_cap; sink.place = place.data(); sink.place_cap = cap.data(); sink.sizes = &sizes; sink.spill = &sp;
+      zpaqhip_err e2{};
+      bool stream_error = false;
+      const int rc = run_pipeline(c, src, sink, opts, false, nullptr, &e2, &stream_error);
+      J.st.kernel_ms += c->stats.kernel_ms; J.st.h2d_ms += c->stats.h2d_ms; J.st.d2h_ms += c->stats.d2h_ms;
+      J.st.blocks += c->stats.blocks; J.st.in_bytes += c->stats.in_bytes; J.st.out_bytes += c->stats.out_bytes;
+      J.st.model_bytes += c->stats.model_bytes; J.st.launches += 1;
+      J.st.concurrent = std::max(J.st.concurrent, c->stats.concurrent); J.st.kernel_kind = std::max(J.st.kernel_kind, c->stats.kernel_kind);
+      size_t good = ids.size();
+      if (rc) {
+        const bool at_block = (stream_error || data_error(rc)) && e2.block >= 0 && (size_t)e2.block < ids.size();
+        if (!at_block) { if (!J.rc) { J.rc = rc; J.err = e2; J.bad = -1; } abort_all = true; break; }   // the call itself failed
+        good = (size_t)e2.block;
+        const long g = (long)ids[good];
+        if (J.bad < 0 || g < J.bad) { J.rc = rc; J.err = e2; J.bad = g; }
+      }
+      for (size_t j = 0; j < good; ++j) { real[ids[j]] = sizes[j]; spill[ids[j]].swap(sp[j]); done[ids[j]] = 1; }
     }
-    SegSink ss;
-    J.rc = run_pipeline(c, src, sink, opts, false, placed ? nullptr : &ss, &J.err);
-    if (!placed && !J.rc && sink.total > sink.cap) {             // the guess was too small: now the size is known
-      J.tmp.resize((size_t)sink.total);
-      Source src2; src2.mem = J.sub.data(); src2.mem_len = J.sub.size();
-      Sinkk sink2; sink2.mem = J.tmp.data(); sink2.cap = J.tmp.size();
-      ss = SegSink();
-      J.rc = run_pipeline(c, src2, sink2, opts, false, &ss, &J.err);
-      sink.total = sink2.total;
-    }
-    if (!placed && !J.rc) {                                       // sizes per block from the per-segment records
-      size_t k = 0;
-      std::vector<uint64_t> per(shard[r].size(), 0);
-      for (size_t i = 0; i < ss.res.size(); ++i) { if (ss.segs[i].block < per.size()) per[ss.segs[i].block] += ss.res[i].out_len; (void)k; }
-      J.sizes = per;
-    }
-    J.total = sink.total;
     zpaqhip_ctx_destroy(c);
   };
-  auto run_all = [&](bool placed) {
+  {
     std::vector<std::thread> th;
-    for (size_t r = 0; r < n_dev; ++r) th.emplace_back(run, r, placed);
+    for (size_t r = 0; r < n_dev; ++r) th.emplace_back(worker, r);
     for (auto &t : th) t.join();
-  };
-  auto first_error = [&]() -> int {                                // the error the reference would reach first
-    int rc = 0; long best = -1;
-    for (size_t r = 0; r < n_dev; ++r) {
-      if (!jobs[r].rc) continue;
-      long g = jobs[r].err.block >= 0 && (size_t)jobs[r].err.block < shard[r].size() ? (long)shard[r][jobs[r].err.block] : 0;
-      if (best < 0 || g < best) { best = g; rc = jobs[r].rc; if (err) { *err = jobs[r].err; err->block = (int32_t)g; err->segment = -1; } }
-    }
-    return rc;
-  };
-  bool placed_ok = false;
-  if (hinted && nb) {
-    run_all(true);
-    int rc = first_error();
-    if (rc && !data_error(rc)) return rc;
-    if (!rc) {
-      placed_ok = true;
-      for (size_t r = 0; r < n_dev && placed_ok; ++r)
-        for (size_t k = 0; k < shard[r].size(); ++k)
-          if (jobs[r].sizes[k] != so.blocks[shard[r][k]].usize_hint) { placed_ok = false; break; }
-    } else return rc;
   }
-  if (!placed_ok && nb) {                                           // no sizes in the comments, or a wrong one
-    run_all(false);
-    int rc = first_error();
-    if (rc) return rc;
-    std::vector<uint64_t> real(nb, 0);
-    for (size_t r = 0; r < n_dev; ++r)
-      for (size_t k = 0; k < shard[r].size(); ++k) real[shard[r][k]] = jobs[r].sizes[k];
-    for (size_t b = 0; b < nb; ++b) final_off[b + 1] = final_off[b] + real[b];
-    if (final_off[nb] <= out_cap)
-      for (size_t r = 0; r < n_dev; ++r) {
-        uint64_t at = 0;
-        for (size_t k = 0; k < shard[r].size(); ++k) {
-          const size_t b = shard[r][k];
-          if (real[b]) memcpy(out + final_off[b], jobs[r].tmp.data() + at, (size_t)real[b]);
-          at += real[b];
-        }
-      }
+  if (per_device) for (size_t r = 0; r < n_dev; ++r) per_device[r] = jobs[r].st;
+  // ---- outcome: a failure of the call itself first; else the first damaged block of the stream
+  for (size_t r = 0; r < n_dev; ++r)
+    if (jobs[r].rc && jobs[r].bad < 0) { if (err) *err = jobs[r].err; return jobs[r].rc; }
+  size_t limit = nb;
+  int data_rc = 0;
+  zpaqhip_err data_err{};
+  for (size_t r = 0; r < n_dev; ++r)
+    if (jobs[r].rc && (size_t)jobs[r].bad < limit) { limit = (size_t)jobs[r].bad; data_rc = jobs[r].rc; data_err = jobs[r].err; data_err.block = (int32_t)limit; data_err.segment = -1; }
+  for (size_t b = 0; b < limit; ++b)
+    if (!done[b]) { set_err(err, ZPAQHIP_E_HIP, (int)b, -1, "multi-device queue: a block was left undecoded"); return ZPAQHIP_E_HIP; }
+  // ---- put the blocks whose size was not the promised one in place
+  std::vector<uint64_t> new_off(limit + 1, 0);
+  bool moved = false;
+  for (size_t b = 0; b < limit; ++b) { new_off[b + 1] = new_off[b] + real[b]; moved |= real[b] != slot_cap[b]; }
+  *out_len = (size_t)new_off[limit];
+  if (new_off[limit] > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, -1, -1); return ZPAQHIP_E_OUTPUT_FULL; }
+  if (moved) {
+    // blocks that lie in their slot (real <= promised) and move up: last first; those that move down: first first;
+    // a block kept in a host buffer is written last, when every other block is where it belongs
+    for (size_t b = limit; b-- > 0;)
+      if (spill[b].empty() && real[b] && new_off[b] > slot_off[b]) memmove(out + new_off[b], out + slot_off[b], (size_t)real[b]);
+    for (size_t b = 0; b < limit; ++b)
+      if (spill[b].empty() && real[b] && new_off[b] < slot_off[b]) memmove(out + new_off[b], out + slot_off[b], (size_t)real[b]);
+    for (size_t b = 0; b < limit; ++b)
+      if (!spill[b].empty()) memcpy(out + new_off[b], spill[b].data(), (size_t)real[b]);
   }
-  *out_len = (size_t)final_off[nb];
-  if (final_off[nb] > out_cap) { set_err(err, ZPAQHIP_E_OUTPUT_FULL, -1, -1); return ZPAQHIP_E_OUTPUT_FULL; }
+  if (data_rc) { if (err) *err = data_err; return data_rc; }
   if (scan_rc) { if (err) *err = scan_err; return scan_rc; }
   return ZPAQHIP_OK;
+}
+
+int zpaqhip_decompress_multi(const int *devices, size_t n_dev, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                             size_t *out_len, const zpaqhip_opts *opts_in, zpaqhip_err *err) {
+  return zpaqhip_decompress_multi_stats(devices, n_dev, in, in_len, out, out_cap, out_len, opts_in, nullptr, err);
 }
 
 int zpaqhip_decompress_segments(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
@@ -1228,7 +1286,7 @@ int zpaqhip_block_pcomp(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint32
   o.struct_size = sizeof o;
   o.max_concurrent = 1;                                  // the block runs in arena slot 0
   o.kernel = 1;                                          // the generic kernel knows how to stop after the header
-  o.reserved[1] = kPpOnlyMagic;
+  o.reserved[0] = kPpOnlyMagic;
   std::vector<zpaqhip_seg_result> res(so.segs.size());
   const uint32_t id = block;
   const uint64_t off0 = 0, cap0 = 0;                     // count-only: nothing is written

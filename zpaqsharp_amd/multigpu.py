@@ -6,9 +6,18 @@ data-path collective.  torch.distributed (RCCL over xGMI on the GPU box, gloo in
 the CPU tests) carries only the block work table and the per-block results —
 KiB-scale traffic:
 
-    all_gather(block weights)  ->  every rank computes the same LPT assignment
-    ... each rank decodes its own blocks, no communication ...
-    all_gather(per-block {status, out_len, checksum})  ->  rank 0 reports
+    broadcast(block table)  ->  every rank derives the same cost-ordered queue
+    ... each rank decodes blocks, no payload communication ...
+    all_gather(per-block {status, out_len})  ->  every rank holds the result table
+
+Who decodes what is either STATIC — longest-processing-time-first over the estimated block
+costs (zpaqhip_block_costs: plaintext bytes x instructions per byte of the block's kernel) — or
+DYNAMIC: the cost-ordered blocks are dealt into chunks of `queue_blocks` (256: one block per CU of
+the GPU that takes the chunk), chunk k = every K-th block of that order, and every rank pulls the
+next chunk from one shared counter whenever it has finished one (`WorkQueue`; the counter is an
+atomic add on the job's rendezvous store, a few bytes per pull), so a GPU that is faster, or
+whose chunks were cheaper than estimated, takes more of them.  Placement does not depend on who
+decodes: the caller gives every block its output offset.
 
 `ShardedJob` is the product entry point: it binds the plan to
 Context.decode_blocks_device(ids = shard) on every rank (bench.py --gpus N and
@@ -18,7 +27,7 @@ be exercised on CPU-only ranks (gloo) in the `-m "not gpu"` tests.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Sequence, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -34,6 +43,57 @@ def lpt_assign(weights: Sequence[int], world: int) -> List[List[int]]:
         shards[r].append(i)
         load[r] += int(weights[i])
     return shards
+
+
+def queue_chunks(costs: Sequence[int], queue_blocks: int = 256) -> List[List[int]]:
+    """The chunks of the dynamic queue (== zpaqhip_decompress_multi): blocks sorted by cost, descending, ties by index;
+    K = ceil(n / queue_blocks) chunks; chunk k = every K-th block of that order starting at k, in stream order.
+    Every chunk is a cross-section of the cost distribution, and the chunks' total costs differ by at most one
+    block's cost per stride."""
+    n = len(costs)
+    if n == 0:
+        return []
+    order = sorted(range(n), key=lambda i: (-int(costs[i]), i))
+    k_chunks = (n + queue_blocks - 1) // queue_blocks
+    return [sorted(order[k::k_chunks]) for k in range(k_chunks)]
+
+
+class LocalCounter:
+    """fetch-and-add for ranks that are threads of one process (tests; zpaqhip_decompress_multi uses std::atomic)."""
+
+    def __init__(self):
+        import threading
+        self._v, self._l = 0, threading.Lock()
+
+    def fetch_add(self, n: int = 1) -> int:
+        with self._l:
+            v = self._v
+            self._v += n
+            return v
+
+
+class StoreCounter:
+    """fetch-and-add on the torch.distributed rendezvous store (TCPStore.add is atomic on the server): the shared head
+    of the block work queue for one-process-per-GPU jobs.  `key` must be new for every pass over the queue."""
+
+    def __init__(self, store, key: str):
+        self.store, self.key = store, key
+
+    def fetch_add(self, n: int = 1) -> int:
+        return int(self.store.add(self.key, n)) - n
+
+
+class WorkQueue:
+    """Chunks of a cost-ordered block list behind one shared counter; `pull()` returns the next chunk's block ids or
+    None when the queue is empty.  Every rank builds the same chunks from the same table, so only the counter is shared."""
+
+    def __init__(self, costs: Sequence[int], counter, queue_blocks: int = 256):
+        self.chunks = queue_chunks(costs, queue_blocks)
+        self.counter = counter
+
+    def pull(self) -> Optional[List[int]]:
+        k = self.counter.fetch_add(1)
+        return self.chunks[k] if k < len(self.chunks) else None
 
 
 def interleave_assign(n_blocks: int, world: int) -> List[List[int]]:
@@ -116,10 +176,23 @@ class ShardedJob:
         self.stream_len = int(h_stream.size)
         self.plan, self.rank, self.dist, self.coll_dev = plan, rank, dist, coll_dev
         self.shard = plan[rank]
+        self.costs = None                                   # filled on first use by decode_dynamic
+        self._passes = 0
+        self.pulled: List[List[int]] = []                   # chunks this rank took in the last dynamic pass
+        self.kernel_ms = 0.0                                # kernel time of this rank's last pass (HIP events, summed over launches)
 
     @staticmethod
-    def _weights(sc):
-        return [sum(int(sc.segments[b.first_seg + s].data_len) for s in range(b.n_seg)) for b in sc.blocks]
+    def _weights(sc, h_stream=None):
+        """Estimated decode cost per block (zpaqhip_block_costs); without the stream (table-only callers): plaintext
+        size from the comment, else 4 x coded bytes."""
+        if h_stream is not None:
+            from . import api
+            return [int(x) for x in api.block_costs(h_stream, sc)]
+        out = []
+        for b in sc.blocks:
+            coded = sum(int(sc.segments[b.first_seg + s].data_len) for s in range(b.n_seg))
+            out.append(int(b.usize_hint) if b.usize_hint != (1 << 64) - 1 and b.usize_hint <= 1 << 40 else 4 * coded)
+        return out
 
     @classmethod
     def single(cls, ctx, stream: np.ndarray, dev):
@@ -163,7 +236,7 @@ class ShardedJob:
         o = 16 + nb * C.sizeof(_lib.Block)
         segs = (_lib.Segment * max(1, ns)).from_buffer_copy(raw[o:o + ns * C.sizeof(_lib.Segment)].ljust(C.sizeof(_lib.Segment), b"\0"))
         sc = api.ScanResult((_lib.Block * nb).from_buffer(blocks), (_lib.Segment * ns).from_buffer(segs))
-        plan = lpt_assign(cls._weights(sc), world)
+        plan = lpt_assign(cls._weights(sc, h_stream), world)
         d_in = torch.from_numpy(np.concatenate([h_stream, np.zeros(16, np.uint8)]))
         if dev is not None:                                  # dev None: CPU-only ranks (tests of the table / plan / gather logic)
             d_in = d_in.to(dev)
@@ -185,6 +258,8 @@ class ShardedJob:
                 segs = [res[blk.first_seg + s] for s in range(blk.n_seg)]
                 local[j, 0] = next((int(r.status) for r in segs if r.status != 0), 0)
                 local[j, 1] = sum(int(r.out_len) for r in segs)
+        if decode_fn is None and mine:
+            self.kernel_ms = float(self.ctx.stats().kernel_ms)
         n = self.sc.n_blocks
         if self.dist is None:
             table = np.zeros((n, 2), np.int64)
@@ -198,4 +273,55 @@ class ShardedJob:
         for r, ids in enumerate(self.plan):
             for j, b in enumerate(ids):
                 table[b] = allres[r, j]
+        return table
+
+    # ---- dynamic form: the ranks pull chunks from one shared queue instead of decoding a fixed shard
+    def _decode_ids(self, ids, d_out, out_off, out_cap, decode_fn, opt):
+        """Decode blocks `ids` to d_out + out_off[b] (offsets indexed by GLOBAL block id) -> [len(ids), 2]."""
+        local = np.zeros((len(ids), 2), np.int64)
+        if decode_fn is not None:
+            local[:] = np.asarray(decode_fn(ids), np.int64).reshape(len(ids), 2)
+            return local
+        rc, res = self.ctx.decode_blocks_device(self.d_in.data_ptr(), self.stream_len, self.sc, d_out.data_ptr(),
+                                                [out_off[b] for b in ids], [out_cap[b] for b in ids],
+                                                ids=ids, h_in=self.h_stream, raise_on_error=False, **opt)
+        self.kernel_ms += float(self.ctx.stats().kernel_ms)
+        for j, b in enumerate(ids):
+            blk = self.sc.blocks[b]
+            segs = [res[blk.first_seg + s] for s in range(blk.n_seg)]
+            local[j, 0] = next((int(r.status) for r in segs if r.status != 0), 0)
+            local[j, 1] = sum(int(r.out_len) for r in segs)
+        return local
+
+    def decode_dynamic(self, d_out, out_off, out_cap, counter=None, queue_blocks: int = 256, decode_fn=None, **opt) -> np.ndarray:
+        """One pass over the whole stream with the ranks pulling chunks from the shared queue (module docstring).
+        `out_off` / `out_cap` are indexed by GLOBAL block id and must be the same on every rank — a block lands at
+        the same offset of whichever rank's `d_out` decodes it.  Returns the [n_blocks, 3] table {status, out_len,
+        rank that decoded it}, gathered from all ranks.  `counter`: fetch_add provider shared by the ranks (default: a
+        StoreCounter on the process group's store, one key per pass)."""
+        if self.costs is None:
+            self.costs = self._weights(self.sc, self.h_stream)
+        self._passes += 1
+        if counter is None:
+            if self.dist is None:
+                counter = LocalCounter()
+            else:
+                from torch.distributed import distributed_c10d as c10d
+                counter = StoreCounter(c10d._get_default_store(), f"zpaqhip/queue/{self._passes}")
+        q = WorkQueue(self.costs, counter, queue_blocks)
+        n = self.sc.n_blocks
+        mine = np.full((n, 3), -1, np.int64)
+        self.pulled, self.kernel_ms = [], 0.0
+        while True:
+            ids = q.pull()
+            if ids is None:
+                break
+            self.pulled.append(ids)
+            mine[ids, :2] = self._decode_ids(ids, d_out, out_off, out_cap, decode_fn, opt)
+            mine[ids, 2] = self.rank
+        if self.dist is None:
+            return mine
+        allres = all_gather_table(mine, self.dist, self.coll_dev)          # [world, n, 3]: each block filled by exactly one rank
+        owner = allres[:, :, 2].argmax(axis=0)                              # the rank whose row is not -1
+        table = allres[owner, np.arange(n)]
         return table
