@@ -507,13 +507,14 @@ def test_multi_device_queue_balances_an_archive_that_mixes_models(ctx):
     costs = z.block_costs(s, sc)
     coded = np.array([int(sc.segments[b.first_seg].data_len) for b in sc.blocks])
     assert costs[2] > 10 * costs[0] * (len(parts[2]) / len(parts[0])) * 0.9 and coded[0] > 0
-    z.decompress_multi([0, 0], s, queue_blocks=4)                 # warm-up: arenas, code objects
-    best = 1.0
+    z.decompress_multi([0, 0], s, queue_blocks=2)                 # warm-up: arenas, code objects
+    best, seen = 1.0, []
     for _ in range(3):
         per = []
-        got = z.decompress_multi([0, 0], s, verify_sha1=True, queue_blocks=4, per_device=per).tobytes()
+        got = z.decompress_multi([0, 0], s, verify_sha1=True, queue_blocks=2, per_device=per).tobytes()
         assert got == want
         k = [float(p_.kernel_ms) for p_ in per]
-        assert sum(int(p_.blocks) for p_ in per) == 120 and sum(int(p_.launches) for p_ in per) == 30
+        seen.append(k)
+        assert sum(int(p_.blocks) for p_ in per) == 120 and sum(int(p_.launches) for p_ in per) == 60
         best = min(best, abs(k[0] - k[1]) / max(k))
-    assert best < 0.10, best
+    assert best < 0.10, seen

@@ -457,7 +457,10 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
         d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr);
         ZH_DEC_STEP(d, 0u, j, bad, rn);                // EOS flag: p = 0
         if (UNLIKELY(bad)) { status = ZH_E_CORRUPT; break; }
-        if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane)) { status = ZH_E_EOF; break; } }
+        // (the 8 bit steps below do not repeat decode()'s range test, Decoder.cs:138: a split keeps low <= curr <= high,
+        // so only a renormalisation can break it, and every renormalisation but the byte's last — which the EOS step of
+        // the next byte covers — raises `bad` itself: dec_renorm_chk)
+        if (UNLIKELY(rn)) { if (dec_renorm_chk(d, in, lane, bad)) { status = ZH_E_EOF; break; } }
         int c;
         if (UNLIKELY(j)) {
           if (d.curr != 0) { status = ZH_E_EOS; break; }
@@ -573,10 +576,14 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             }
             const int sqp = (int)*(lds_u16_p)((uint32_t)(uintptr_t)lds_squash + (uint32_t)(p + 2048) * 2u);
             if (!SP::smem_ps) ps = (rdlane((uint32_t)sqp, SP::final_lane) * 2 + 1) << 16;
-            uint32_t jb = j;
-            ZH_DEC_STEP(d, ps, jb, bad, rn);
+            uint32_t jb = j, xr;
+            ZH_DEC_STEP_LITE(d, ps, jb, xr);
             j = jb;
-            if (UNLIKELY(rn)) { if (dec_renorm(d, in, lane) && !err) err = bad ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF; }
+            if (UNLIKELY(xr < 0x1000000u)) {
+              const uint32_t was = bad;
+              uint32_t later = 0;                         // after the byte's last bit the next EOS step re-checks by itself
+              if (dec_renorm_chk(d, in, lane, bit == 7 ? later : bad) && !err) err = was ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF;
+            }
             const uint32_t y = uni(j & 1);
             const int ey = y ? 32767 : 0;
             C2_STAMP(2);

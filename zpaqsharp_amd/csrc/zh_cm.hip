@@ -54,7 +54,7 @@ constexpr uint32_t kSpinSection = 1u << 27;   // bounded waits: nothing may hang
 constexpr uint64_t kSpinIdle = 1ull << 33;
 #define ZH_E_HELPER (-24)                  // = ZPAQHIP_E_HIP: the helper wavefront stopped answering (cannot happen by design)
 
-struct alignas(16) CmLds {
+struct alignas(64) CmLds {
   int16_t sh[16384];                      // stretch(x) for x in [16384, 32768); stretch(x) = -stretch(32767 - x) below
   uint16_t sq[4096];                      // squash
   int32_t dt[1024];
@@ -62,7 +62,8 @@ struct alignas(16) CmLds {
   uint32_t winA[kWin][16];                // CM entries of group 0 (first nibble)
   uint16_t p16B[kWin][256];               // predict()*2+1 of every winB entry, order p16b_pos; kept current by wave B
   uint16_t p16A[kWin][16];                // same for winA
-  uint32_t ring[kRing];                   // A -> B messages: tag(7) | type(2) | byte(8) | 0(9) | slot(6)
+  alignas(64) uint32_t ring[kRing];       // A -> B messages: tag(7) | type(2) | byte(8) | 0(9) | slot(6); 64-byte aligned (zh_cm_fast.h steps the address with v_bfi)
+  uint32_t dummy[64];                     // where the lanes of wave A other than lane 0 put their copy of a message (no exec switch)
   uint32_t aux[kRing][2];                 // MISS: new window, victim window
   uint32_t tags[64];                      // ENTER: slot s was trained by wave A alone since B last saw it (its p16 is stale)
   uint32_t t0, b_seq;                     // message count at section start / messages completed by B
@@ -324,6 +325,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
   // four second-nibble candidates of quad lgrp (+ slot * 512)
   const uint32_t p_la = lds_off(&S.p16A[0][0]) + l15 * 2, p_lb = lds_off(&S.p16B[0][0]) + lgrp * 128 + l15 * 8;
   const uint32_t ring_addr = lds_off(&S.ring[0]), bseq_addr = lds_off(&S.b_seq);
+  const uint32_t dummy_addr = lds_off(&S.dummy[lane]), ring_step = lane == 0 ? 63u : 0u;   // see ZH_FAST_EPILOGUE
 
   uint8_t *slot_mem = L.arena + (uint64_t)blockIdx.x * L.arena_stride;
 
@@ -342,6 +344,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
     const uint32_t cm_mask = uni(cp->cm_mask);
     const uint32_t limit = (uint32_t)uni(cp->arg[1]) * 4;
     const uint64_t cm_off = uni64(cp->cm_off), cm_bytes = uni64(cp->cm_bytes);
+    const uint32_t win_bfe = 9u | ((uint32_t)__builtin_popcount(cm_mask) - 9u) << 16;   // s_bfe operand: window id = bits 9.. of h[0] & cm_mask
     const uint32_t hshift = (uni(M->kind) >> 16) & 255;    // HCOMP "a<<= K  *d=a  halt": 9 <= K <= 31 (zh_framing.cpp)
     uint32_t *table = reinterpret_cast<uint32_t *>(slot_mem + cm_off);
 
@@ -569,8 +572,12 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
               uint64_t f0 = 0, f1 = 0;
               const uint32_t t_in = t;
               if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(f0)::"memory"); }
-              ZH_CM_FAST_LOOP(d.low, d.high, d.curr, in.k, t, h0, b_done, lastuse, code, in.avail, uni(cm_mask), uni(hshift),
-                              uni(ring_addr), bseq_addr, in.cur, tag, lane, p_la, p_lb);
+              if (LIKELY(d.curr - d.low <= d.high - d.low)) {   // the loop's invariant (an out-of-range state is the C++ body's to report)
+                const uint32_t klim = uni(in.avail >= 40 ? in.avail - 40 : 0u);
+                uint32_t vr = lane == 0 ? ring_addr + (t & (kRing - 1)) * 4u : dummy_addr;
+                ZH_CM_FAST_LOOP(d.low, d.high, d.curr, in.k, t, h0, b_done, lastuse, code, klim, uni(win_bfe), uni(hshift),
+                                vr, ring_step, bseq_addr, in.cur, tag, p_la, p_lb);
+              } else code = 0;
               if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(f1)::"memory"); prof[2] += f1 - f0; prof[3] += t - t_in; }
               if (UNLIKELY(code)) { ev = kEvCorrupt; d.low = d.high = d.curr = 1; }   // the EOS test below ends the section
             }

@@ -10,15 +10,15 @@
 //     a renormalisation never has to refill or can hit EOF;
 //   * the context's window is resident (otherwise wave B must swap it in);
 //   * wave B has finished every earlier byte that touched that window and the ring has room;
-//   * the EOS flag decodes as 0 and the state is in range (Decoder.cs:138); an unprimed coder
-//     (curr == 0 < low) fails this test too, so priming needs no test of its own.
+//   * the EOS flag decodes as 0 (Decoder.cs:138; the state is in range by the invariant stated at the
+//     loop); an unprimed coder (curr == 0 < low) fails this test too, so priming needs no test of its own.
 // If any test fails it leaves with code 0 and the C++ body of the loop in zh_cm.hip handles that
 // byte (it is the same algorithm, including the rare cases), then re-enters.  Code 1 = the range
 // check after a renormalisation failed ("archive corrupted").
 //
-// Per decoded bit: v_readlane (probability of tree node j), 10 SALU instructions for the split
-// (Decoder.cs:140-147; mulhi against p16 << 16 replaces the 64-bit multiply and shift), and a
-// compare + branch for the renormalisation, which is out of line.
+// Per decoded bit: v_readlane (probability of tree node j), 9 SALU instructions for the split
+// (Decoder.cs:140-147; mulhi against p16 << 16 replaces the 64-bit multiply and shift; y = curr <= mid
+// as the reference words it), and a compare + branch for the renormalisation, which is out of line.
 //
 // Register use: operands are allocated by the compiler; temporaries are the fixed registers
 // s80-s94 and v250-v252 (declared as clobbers).  exec is all ones on entry and exit.
@@ -28,11 +28,10 @@
 #define ZH_FAST_STEP(PV, J, IDX, N)                                   \
   "v_readlane_b32 s94, " PV ", " IDX "\n\t"                           \
   "s_sub_u32 s84, %[high], %[low]\n\t"                                \
-  "s_sub_u32 s85, %[curr], %[low]\n\t"                                \
   "s_mul_hi_u32 s86, s84, s94\n\t"                                    \
   "s_add_u32 s87, %[low], s86\n\t"                                    \
   "s_add_u32 s88, s87, 1\n\t"                                         \
-  "s_cmp_le_u32 s85, s86\n\t"                                         \
+  "s_cmp_le_u32 %[curr], s87\n\t"                                     \
   "s_cselect_b32 %[high], s87, %[high]\n\t"                           \
   "s_cselect_b32 %[low], %[low], s88\n\t"                             \
   "s_addc_u32 " J ", " J ", " J "\n\t"                                \
@@ -42,8 +41,7 @@
   ".Lzh_bk" #N "_%=:\n\t"
 
 // Renormalisation (Decoder.cs:148-156): shift a coded byte in while the top bytes of low and
-// high agree; then the range test the next decode() would make (skipped after the byte's last
-// bit, where the next call re-primes and re-checks by itself).
+// high agree; then the range test the next decode() would make (after the byte's last bit: ZH_FAST_CHK8).
 #define ZH_FAST_RENORM(N, CHK)                                        \
   ".Lzh_rn" #N "_%=:\n\t"                                             \
   "s_lshl_b32 %[high], %[high], 8\n\t"                                \
@@ -70,16 +68,51 @@
   "s_cmp_gt_u32 %[curr], %[high]\n\t"                                 \
   "s_cselect_b32 s93, 1, s93\n\t"
 
+// The last bit's renormalisation: a state out of range is not an error of THIS byte (Decoder.cs:138 raises it at the
+// next decode() call), so the byte is still published and the loop is left; the C++ body's EOS test reports it.
+#define ZH_FAST_CHK8                                                  \
+  "s_cmp_lt_u32 %[curr], %[low]\n\t"                                  \
+  "s_cbranch_scc1 .Lzh_oor_%=\n\t"                                    \
+  "s_cmp_gt_u32 %[curr], %[high]\n\t"                                 \
+  "s_cbranch_scc1 .Lzh_oor_%=\n\t"
+
+// byte = (j << 4) + j2 - 272;  message to wave B: tag(t) << 25 | byte << 15 | slot, written by lane 0 to the ring slot
+// of message t (the other lanes of `vr` hold the addresses of their own dummy words: no exec switch around the write);
+// then the ring address of lane 0 steps on (v_bfi keeps the other lanes), t, the slot's last-use stamp (vcc still is
+// the one-hot lane mask of the window lookup: nothing in the loop writes vcc after it), h[0]
+#define ZH_FAST_EPILOGUE                                              \
+  "s_lshl4_add_u32 s92, s90, s91\n\t"                                 \
+  "s_add_u32 s92, s92, 0xfffffef0\n\t"                                \
+  "s_lshl_b32 s80, %[t], 21\n\t"                                      \
+  "s_and_b32 s80, s80, 0xfe000000\n\t"                                \
+  "s_lshl_b32 s84, s92, 15\n\t"                                       \
+  "s_or_b32 s80, s80, s84\n\t"                                        \
+  "s_or_b32 s80, s80, s82\n\t"                                        \
+  "v_mov_b32_e32 v250, s80\n\t"                                       \
+  "ds_write_b32 %[vr], v250\n\t"                                      \
+  "v_add_u32_e32 v252, 4, %[vr]\n\t"                                  \
+  "v_bfi_b32 %[vr], %[vm], v252, %[vr]\n\t"                           \
+  "s_add_u32 %[t], %[t], 1\n\t"                                       \
+  "v_mov_b32_e32 v252, %[t]\n\t"                                      \
+  "v_cndmask_b32_e32 %[lu], %[lu], v252, vcc\n\t"                     \
+  "s_lshl_b32 %[h0], s92, %[hs]\n\t"
+
 // s80 scratch   s81 window id   s82 slot   s83 back   s84-s88 step scratch   s89 lag
 // s90 j (16|n1) s91 j2 (16|n2)  s92 byte   s93 bad    s94 probability
-// v250:v251 four second-nibble probabilities / selected one   v252 first-nibble probabilities, scratch
-#define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, avail_, mask_, hs_, ring_, bsa_, cur_, tag_, lid_, la_, lb_) \
+// v250:v251 four second-nibble probabilities / selected one   v252 scratch
+// v249 first-nibble probabilities << 16 (loaded into the high half: ds_read_u16_d16_hi; its low half stays zero)
+//
+// Invariant on entry and at every .Lzh_byte: low <= curr <= high unless the coder is unprimed (curr == 0 < low) — every
+// renormalisation inside the loop re-checks it (ZH_FAST_CHK / ZH_FAST_CHK8), a split keeps it — so the EOS flag (p = 0:
+// y = curr <= low) needs one compare.  zh_cm.hip enters the loop only with the state in range.
+#define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_) \
   asm volatile(                                                       \
+  "s_mov_b32 s93, 0\n\t"                                              \
+  "v_mov_b32_e32 v249, 0\n\t"                                         \
   ".p2align 8\n"                                                      \
   ".Lzh_byte_%=:\n\t"                                                 \
   /* window lookup: lane s of `tag` holds the window id cached in slot s */ \
-  "s_and_b32 s81, %[h0], %[mask]\n\t"                                 \
-  "s_lshr_b32 s81, s81, 9\n\t"                                        \
+  "s_bfe_u32 s81, %[h0], %[bfe]\n\t"                                  \
   "v_cmp_eq_u32_e32 vcc, s81, %[tag]\n\t"                             \
   "s_cbranch_vccz .Lzh_slow_%=\n\t"                                   \
   "s_ff1_i32_b64 s82, vcc\n\t"                                        \
@@ -93,34 +126,27 @@
   ".Lzh_ok_%=:\n\t"                                                   \
   /* cached probabilities: lane j <- node j of the first nibble; lane (q, j) <- node j of groups q, q+4, q+8, q+12. */ \
   /* Issued before the remaining tests so that their latency is covered; a slow exit waits for them. */ \
-  "s_lshl_b32 s80, s82, 5\n\t"                                        \
-  "s_lshl_b32 s84, s82, 9\n\t"                                        \
-  "v_add_u32_e32 v252, s80, %[la]\n\t"                                \
-  "v_add_u32_e32 v250, s84, %[lb]\n\t"                                \
-  "ds_read_u16 v252, v252\n\t"                                        \
+  "v_lshl_add_u32 v252, s82, 5, %[la]\n\t"                            \
+  "v_lshl_add_u32 v250, s82, 9, %[lb]\n\t"                            \
+  "ds_read_u16_d16_hi v249, v252\n\t"                                 \
   "ds_read_b64 v[250:251], v250\n\t"                                  \
-  "s_sub_u32 s80, %[avail], %[k]\n\t"                                 \
-  "s_cmp_lt_u32 s80, 40\n\t"                                          \
+  /* at least 40 coded bytes in the chunk (klim = avail - 40, or 0) */ \
+  "s_cmp_ge_u32 %[k], %[klim]\n\t"                                    \
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
-  /* EOS flag (p = 0): y = curr <= low; leave when y = 1 or curr is out of range */ \
-  "s_sub_u32 s80, %[curr], %[low]\n\t"                                \
-  "s_sub_u32 s84, %[high], %[low]\n\t"                                \
-  "s_add_u32 s80, s80, -1\n\t"                                        \
-  "s_cmp_ge_u32 s80, s84\n\t"                                         \
+  /* EOS flag (p = 0): y = curr <= low; leave when y = 1 (or the coder is unprimed) */ \
+  "s_cmp_le_u32 %[curr], %[low]\n\t"                                  \
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
   "s_add_u32 %[low], %[low], 1\n\t"                                   \
-  "s_mov_b32 s93, 0\n\t"                                              \
   "s_mov_b32 s90, 1\n\t"                                              \
   "s_xor_b32 s84, %[high], %[low]\n\t"                                \
   "s_cmp_lt_u32 s84, 0x1000000\n\t"                                   \
   "s_cbranch_scc1 .Lzh_rn0_%=\n"                                      \
   ".Lzh_bk0_%=:\n\t"                                                  \
   "s_waitcnt lgkmcnt(1)\n\t"                                          \
-  "v_lshlrev_b32_e32 v252, 16, v252\n\t"                              \
-  ZH_FAST_STEP("v252", "s90", "s90", 1)                               \
-  ZH_FAST_STEP("v252", "s90", "s90", 2)                               \
-  ZH_FAST_STEP("v252", "s90", "s90", 3)                               \
-  ZH_FAST_STEP("v252", "s90", "s90", 4)                               \
+  ZH_FAST_STEP("v249", "s90", "s90", 1)                               \
+  ZH_FAST_STEP("v249", "s90", "s90", 2)                               \
+  ZH_FAST_STEP("v249", "s90", "s90", 3)                               \
+  ZH_FAST_STEP("v249", "s90", "s90", 4)                               \
   /* second nibble: group n1 = quad (n1 & 3), element n1 >> 2 */      \
   "s_lshl_b32 s80, s90, 2\n\t"                                        \
   "s_and_b32 s80, s80, 48\n\t"                                        \
@@ -140,27 +166,7 @@
   ZH_FAST_STEP("v250", "s91", "s80", 8)                               \
   "s_cmp_lg_u32 s93, 0\n\t"                                           \
   "s_cbranch_scc1 .Lzh_corrupt_%=\n\t"                                \
-  /* byte = (j << 4) + j2 - 272;  message to wave B: tag(t) << 25 | byte << 15 | slot */ \
-  "s_lshl4_add_u32 s92, s90, s91\n\t"                                 \
-  "s_add_u32 s92, s92, 0xfffffef0\n\t"                                \
-  "s_lshl_b32 s80, %[t], 21\n\t"                                      \
-  "s_and_b32 s80, s80, 0xfe000000\n\t"                                \
-  "s_lshl_b32 s84, s92, 15\n\t"                                       \
-  "s_or_b32 s80, s80, s84\n\t"                                        \
-  "s_or_b32 s80, s80, s82\n\t"                                        \
-  "s_and_b32 s84, %[t], 15\n\t"                                       \
-  "s_lshl_b32 s84, s84, 2\n\t"                                        \
-  "s_add_u32 s84, s84, %[ring]\n\t"                                   \
-  "v_mov_b32_e32 v252, s84\n\t"                                       \
-  "v_mov_b32_e32 v250, s80\n\t"                                       \
-  "s_mov_b64 exec, 1\n\t"                                             \
-  "ds_write_b32 v252, v250\n\t"                                       \
-  "s_mov_b64 exec, -1\n\t"                                            \
-  "s_add_u32 %[t], %[t], 1\n\t"                                       \
-  "v_cmp_eq_u32_e32 vcc, s82, %[lid]\n\t"                             \
-  "v_mov_b32_e32 v252, %[t]\n\t"                                      \
-  "v_cndmask_b32_e32 %[lu], %[lu], v252, vcc\n\t"                     \
-  "s_lshl_b32 %[h0], s92, %[hs]\n\t"                                  \
+  ZH_FAST_EPILOGUE                                                    \
   "s_branch .Lzh_byte_%=\n"                                           \
   /* ---- out of line ---- */                                         \
   /* wave B is behind: re-read its progress counter a bounded number of times, then give up */ \
@@ -185,7 +191,12 @@
   ZH_FAST_RENORM(5, ZH_FAST_CHK)                                      \
   ZH_FAST_RENORM(6, ZH_FAST_CHK)                                      \
   ZH_FAST_RENORM(7, ZH_FAST_CHK)                                      \
-  ZH_FAST_RENORM(8, "")                                               \
+  ZH_FAST_RENORM(8, ZH_FAST_CHK8)                                     \
+  ".Lzh_oor_%=:\n\t"                                                  \
+  "s_cmp_lg_u32 s93, 0\n\t"                                           \
+  "s_cbranch_scc1 .Lzh_corrupt_%=\n\t"                                \
+  ZH_FAST_EPILOGUE                                                    \
+  "s_branch .Lzh_slow_%=\n"                                           \
   ".Lzh_corrupt_%=:\n\t"                                              \
   "s_mov_b32 %[code], 1\n\t"                                          \
   "s_branch .Lzh_end_%=\n"                                            \
@@ -194,9 +205,9 @@
   "s_mov_b32 %[code], 0\n"                                            \
   ".Lzh_end_%=:\n\t"                                                  \
   : [low] "+s"(low_), [high] "+s"(high_), [curr] "+s"(curr_), [k] "+s"(k_), [t] "+s"(t_), [h0] "+s"(h0_), \
-    [bdone] "+s"(bdone_), [lu] "+v"(lu_), [code] "=s"(code_)          \
-  : [avail] "s"(avail_), [mask] "s"(mask_), [hs] "s"(hs_), [ring] "s"(ring_), [bsa] "v"(bsa_),             \
-    [cur] "v"(cur_), [tag] "v"(tag_), [lid] "v"(lid_), [la] "v"(la_), [lb] "v"(lb_)                        \
+    [bdone] "+s"(bdone_), [lu] "+v"(lu_), [vr] "+v"(vr_), [code] "=s"(code_)          \
+  : [klim] "s"(klim_), [bfe] "s"(bfe_), [hs] "s"(hs_), [vm] "v"(vm_), [bsa] "v"(bsa_),             \
+    [cur] "v"(cur_), [tag] "v"(tag_), [la] "v"(la_), [lb] "v"(lb_)                        \
   : "memory", "scc", "vcc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",   \
-    "s91", "s92", "s93", "s94", "v250", "v251", "v252")
+    "s91", "s92", "s93", "s94", "v249", "v250", "v251", "v252")
 // clang-format on

@@ -153,20 +153,19 @@ struct Dec { uint32_t low, high, curr; };
 // renormalisation can break the invariant, and dec_renorm_chk reports exactly that.
 #define ZH_DEC_STEP_LITE(d, ps, j, x)                                                               \
   do {                                                                                              \
-    uint32_t r_, t_, off_, mid_, m1_;                                                               \
+    uint32_t r_, off_, mid_, m1_;                                                                   \
     asm volatile(                                                                                   \
         "s_sub_u32 %[r], %[high], %[low]\n\t"                                                       \
-        "s_sub_u32 %[t], %[curr], %[low]\n\t"                                                       \
         "s_mul_hi_u32 %[off], %[r], %[p]\n\t"                                                       \
         "s_add_u32 %[mid], %[low], %[off]\n\t"                                                      \
         "s_add_u32 %[m1], %[mid], 1\n\t"                                                            \
-        "s_cmp_le_u32 %[t], %[off]\n\t"                                                             \
+        "s_cmp_le_u32 %[curr], %[mid]\n\t"                                                          \
         "s_cselect_b32 %[high], %[mid], %[high]\n\t"                                                \
         "s_cselect_b32 %[low], %[low], %[m1]\n\t"                                                   \
         "s_addc_u32 %[jj], %[jj], %[jj]\n\t"                                                        \
         "s_xor_b32 %[xx], %[high], %[low]"                                                          \
         : [low] "+s"(d.low), [high] "+s"(d.high), [curr] "+s"(d.curr), [jj] "+s"(j), [xx] "=s"(x),  \
-          [r] "=&s"(r_), [t] "=&s"(t_), [off] "=&s"(off_), [mid] "=&s"(mid_), [m1] "=&s"(m1_)       \
+          [r] "=&s"(r_), [off] "=&s"(off_), [mid] "=&s"(mid_), [m1] "=&s"(m1_)                      \
         : [p] "s"(ps)                                                                               \
         : "scc");                                                                                   \
   } while (0)
