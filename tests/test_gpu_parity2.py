@@ -490,10 +490,10 @@ def test_multi_device_entry_point_with_contexts_sharing_this_gpu(ctx):
         z.decompress_multi([0, 0], bytes(bad))
 
 
-def test_multi_device_queue_balances_an_archive_that_mixes_models(ctx):
+def test_multi_device_queue_on_an_archive_that_mixes_models(ctx):
     """An archive of l1 / mid / max blocks of uneven sizes, two contexts on this GPU pulling from the cost-ordered queue:
-    bit-exact, and the kernel time of the two device threads ends within 10 % of each other.  (By coded bytes — the
-    round-2 weight — an l1 block outweighs a max block of the same plaintext although it decodes 18 x faster.)"""
+    bit-exact, every block decoded once, both device threads at work.  (Kernel times of two contexts that share one GPU say
+    nothing about balance — their allocations and kernels serialise each other; the plan's balance is measured below.)"""
     rng = np.random.default_rng(12)
     parts, blocks = [], []
     for i in range(120):
@@ -503,18 +503,48 @@ def test_multi_device_queue_balances_an_archive_that_mixes_models(ctx):
         blocks.append(synth.compress_block(model, np.frombuffer(d, np.uint8)))
     s = b"".join(blocks)
     want = b"".join(parts)
-    sc = z.scan(s)
-    costs = z.block_costs(s, sc)
-    coded = np.array([int(sc.segments[b.first_seg].data_len) for b in sc.blocks])
-    assert costs[2] > 10 * costs[0] * (len(parts[2]) / len(parts[0])) * 0.9 and coded[0] > 0
-    z.decompress_multi([0, 0], s, queue_blocks=2)                 # warm-up: arenas, code objects
-    best, seen = 1.0, []
-    for _ in range(3):
-        per = []
-        got = z.decompress_multi([0, 0], s, verify_sha1=True, queue_blocks=2, per_device=per).tobytes()
-        assert got == want
-        k = [float(p_.kernel_ms) for p_ in per]
-        seen.append(k)
-        assert sum(int(p_.blocks) for p_ in per) == 120 and sum(int(p_.launches) for p_ in per) == 60
-        best = min(best, abs(k[0] - k[1]) / max(k))
-    assert best < 0.10, seen
+    per = []
+    got = z.decompress_multi([0, 0], s, verify_sha1=True, queue_blocks=2, per_device=per).tobytes()
+    assert got == want
+    assert sum(int(p_.blocks) for p_ in per) == 120 and sum(int(p_.launches) for p_ in per) == 60
+    assert min(int(p_.launches) for p_ in per) >= 10, [int(p_.launches) for p_ in per]
+
+
+def test_cost_weighted_plan_balances_kernel_time_on_an_archive_that_mixes_models(ctx):
+    """The weights of the multi-GPU plan (zpaqhip_block_costs: plaintext bytes x instructions per byte of the block's
+    kernel) against the clock: 1 800 blocks of the l1 / mid / max models in three sizes (more blocks per kernel family and
+    shard than the GPU has CUs, so a shard's kernel time is its work, not its longest block), dealt to two ranks
+    longest-first; each rank's shard is decoded by zpaqhip_decode_blocks_device(ids = shard) — one after the other on
+    this box's one GPU — and their kernel times (HIP events) must agree within 10 %.  The round-2 weights (coded bytes)
+    put an l1 block above a max block of the same plaintext although it decodes 18 x faster: their plan is timed beside it."""
+    import torch
+    from zpaqsharp_amd import multigpu
+    streams = []
+    for mi, model in enumerate(("l1", "mid", "max")):
+        for si, size in enumerate((4096, 8192, 16384)):
+            st, _ = synth.stream(model, "T", nblocks=200, block_size=size, first_block=1000 * (3 * mi + si), threads=8)
+            streams.append(st)
+    stream = np.concatenate(streams)
+    dev = torch.device("cuda", 0)
+    job = multigpu.ShardedJob.single(ctx, stream, dev)
+    sc = job.sc
+    assert sc.n_blocks == 1800
+    sizes = [int(b.usize_hint) for b in sc.blocks]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    d_out = torch.zeros(int(off[-1]), dtype=torch.uint8, device=dev)
+    costs = [int(x) for x in z.block_costs(stream, sc)]
+    coded = [sum(int(sc.segments[b.first_seg + i].data_len) for i in range(b.n_seg)) for b in sc.blocks]
+
+    def run(plan):
+        times = []
+        for shard in plan:
+            job.shard = shard
+            for _ in range(2):                                   # (the first pass of a shard allocates)
+                t = job.decode(d_out, [int(off[b]) for b in shard], [sizes[b] for b in shard], verify_sha1=True)
+            assert all(int(t[b, 0]) == 0 and int(t[b, 1]) == sizes[b] for b in shard)
+            times.append(job.kernel_ms)
+        return times
+    k = run(multigpu.lpt_assign(costs, 2))
+    assert abs(k[0] - k[1]) / max(k) < 0.10, k
+    k_old = run(multigpu.lpt_assign(coded, 2))
+    print("kernel ms per rank: cost-weighted plan", k, "coded-bytes plan", k_old)

@@ -72,14 +72,20 @@ def byte_loop(ins, nsteps=9):
             tgt = a + 4 + 4 * rel
             if tgt in addr_ix and addr_ix[tgt] <= i:
                 loops.append((addr_ix[tgt], i))
+    # the byte loop = the loop closed by the FIRST backward branch behind the last step that encloses all the steps and
+    # no other decoder step (backward branches of polling / retry paths laid out behind the loop close larger ranges)
     best = None
     for w in range(len(steps) - nsteps + 1):
         grp = steps[w:w + nsteps]
+        mine = None
         for lo, hi in loops:
             if lo <= grp[0] and grp[-1] <= hi:
                 n_in = sum(1 for s_ in steps if lo <= s_ <= hi)
-                if n_in == nsteps and (best is None or hi - lo < best[1] - best[0]):
-                    best = (lo, hi, grp)
+                if n_in == nsteps and (mine is None or hi < mine[1] or (hi == mine[1] and lo > mine[0])):
+                    mine = (lo, hi, grp)
+        # several groups (the hand-written loop of zh_cm_fast.h and the C++ body of the same loop): the tightest loop is the hot one
+        if mine and (best is None or mine[1] - mine[0] < best[1] - best[0]):
+            best = mine
     return best
 
 

@@ -44,7 +44,7 @@ namespace {
 // Diagnostic build (PROF): cycles per stage, summed per block into L.debug[0..7].  Stamps wait for LDS/scalar results
 // only (global memory stays in flight, as in the real kernel).
 #ifndef C2_PROF_MASK
-#define C2_PROF_MASK 0xfff                      /* stages the *_prof kernels stamp (fewer stamps: less distortion) */
+#define C2_PROF_MASK 0x1fff                     /* stages the *_prof kernels stamp (fewer stamps: less distortion) */
 #endif
 #define C2_STAMP(i)                                                                                  \
   do {                                                                                               \
@@ -62,7 +62,7 @@ __device__ __forceinline__ void c2_wave_sync() { __builtin_amdgcn_fence(__ATOMIC
 
 template <class SP, bool PROF, int HELP, class LDS>
 __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
-  uint64_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tprev = 0;
   const uint32_t lane = threadIdx.x & 63u;
   const bool wave_a = (threadIdx.x >> 6) == 0;
@@ -479,6 +479,13 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             const bool pre_ii = (bit & 3) != 3;          // the next bit stays in this nibble: fetch both of its nodes
             const bool pre_mx = bit != 7;                // the next bit stays in this byte: fetch both of its mixer rows
             hm = uni(hm); c8 = uni(c8);
+            if (PROF && ((C2_PROF_MASK >> 12) & 1)) {   // diagnostic: what is still in flight from the bit before (loads and stores), drained here
+              uint64_t now_;
+              __builtin_amdgcn_sched_barrier(0);
+              asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");
+              __builtin_amdgcn_sched_barrier(0);
+              prof[12] += now_ - tprev; tprev = now_;
+            }
             // ---- (a) requests for the NEXT bit, both ways
             if (SP::match_lane >= 0 && bit == 4) match_prefetch();
             uint32_t ea0 = 0, ea1 = 0;
@@ -829,7 +836,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
       }
     }
     if (PROF && lane == 0 && L.debug)
-      for (int i = 0; i < 12; ++i) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
+      for (int i = 0; i < 16; ++i) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
     if (HELP) {                                         // the helper wave leaves the block; its late commit of the last byte
       ++cmd_seq;                                        // (S.mreg / S.hreg) must be in LDS before this wave zeroes them again
       c2_put0(&S.mb_cmd, cmd_seq << 2 | kC2End);

@@ -103,7 +103,7 @@ __device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(u
 // quad q & 3, position, element q >> 2 — so that the four candidates of a lane of wave A (groups
 // q, q+4, q+8, q+12, same position) are adjacent: one ds_read_b64.
 __device__ __forceinline__ uint32_t p16b_pos(uint32_t q, uint32_t P) { return ((q & 3) << 6) | (P << 2) | (q >> 2); }
-__device__ __forceinline__ uint32_t ring_tag(uint32_t u) { return (u >> 4) & 127u; }   // kRing == 16
+__device__ __forceinline__ uint32_t ring_tag(uint32_t u) { return u & 127u; }   // differs between the messages u, u + 16, ... u + 112 that share a ring entry
 static_assert(kRing == 16, "ring_tag");
 // single-wave replacement of __syncthreads(): wave A must never wait on a workgroup barrier (wave B idles in a mailbox loop)
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }

@@ -16,16 +16,27 @@
 // byte (it is the same algorithm, including the rare cases), then re-enters.  Code 1 = the range
 // check after a renormalisation failed ("archive corrupted").
 //
-// Per decoded bit: v_readlane (probability of tree node j), 9 SALU instructions for the split
+// Per decoded bit: v_readlane (probability of tree node j), 8 SALU instructions for the split
 // (Decoder.cs:140-147; mulhi against p16 << 16 replaces the 64-bit multiply and shift; y = curr <= mid
-// as the reference words it), and a compare + branch for the renormalisation, which is out of line.
+// as the reference words it), and xor + compare + branch for the renormalisation, which is out of line.
 //
 // Register use: operands are allocated by the compiler; temporaries are the fixed registers
 // s80-s94 and v250-v252 (declared as clobbers).  exec is all ones on entry and exit.
 #pragma once
 
 // clang-format off
-#define ZH_FAST_STEP(PV, J, IDX, N)                                   \
+#define ZH_FAST_STEP(PV, J, IDX, N) ZH_FAST_STEP_(PV, IDX, N, "s_addc_u32 " J ", " J ", " J)
+#define ZH_FAST_STEP1(PV, J, IDX, N) ZH_FAST_STEP_(PV, IDX, N, "s_addc_u32 " J ", 1, 1")   /* first step of a nibble: node 1 */
+// The renormalisation test for the split of bit N-1 (or the EOS flag's low + 1) sits at the START of step N, behind
+// the v_readlane of step N's probability: the three scalar instructions cover most of the VALU -> SALU hand-over that the
+// multiply would otherwise wait out (tools/ubench/step_bench: ~24 cycles).  Nothing between a split and this test reads
+// low / high / curr, so it is the reference's order of events (Decoder.cs:148-156 runs right after the split).
+// (Testing high - low < 2^24 instead — one instruction less, the step needs the range anyway — was measured and lost 6 %:
+// ranges below 2^24 whose top bytes differ are common, and each sends the wave out of line for nothing.)
+// (Measured on the same GPU box and not kept: the renormalisation test of bit N-1 moved behind step N's v_readlane —
+// 554 against 565 MB/s; the test replaced by `high - low < 2^24`, which the step computes anyway — 531 MB/s: ranges
+// below 2^24 whose top bytes differ are common, and each one sends the wave out of line for nothing.)
+#define ZH_FAST_STEP_(PV, IDX, N, ADDC)                               \
   "v_readlane_b32 s94, " PV ", " IDX "\n\t"                           \
   "s_sub_u32 s84, %[high], %[low]\n\t"                                \
   "s_mul_hi_u32 s86, s84, s94\n\t"                                    \
@@ -34,7 +45,7 @@
   "s_cmp_le_u32 %[curr], s87\n\t"                                     \
   "s_cselect_b32 %[high], s87, %[high]\n\t"                           \
   "s_cselect_b32 %[low], %[low], s88\n\t"                             \
-  "s_addc_u32 " J ", " J ", " J "\n\t"                                \
+  ADDC "\n\t"                                                         \
   "s_xor_b32 s84, %[high], %[low]\n\t"                                \
   "s_cmp_lt_u32 s84, 0x1000000\n\t"                                   \
   "s_cbranch_scc1 .Lzh_rn" #N "_%=\n"                                 \
@@ -42,8 +53,8 @@
 
 // Renormalisation (Decoder.cs:148-156): shift a coded byte in while the top bytes of low and
 // high agree; then the range test the next decode() would make (after the byte's last bit: ZH_FAST_CHK8).
-#define ZH_FAST_RENORM(N, CHK)                                        \
-  ".Lzh_rn" #N "_%=:\n\t"                                             \
+#define ZH_FAST_SHIFT_IN(N)                                           \
+  ".Lzh_rl" #N "_%=:\n\t"                                             \
   "s_lshl_b32 %[high], %[high], 8\n\t"                                \
   "s_or_b32 %[high], %[high], 0xff\n\t"                               \
   "s_lshl_b32 %[low], %[low], 8\n\t"                                  \
@@ -58,15 +69,25 @@
   "s_add_u32 %[k], %[k], 1\n\t"                                       \
   "s_xor_b32 s84, %[high], %[low]\n\t"                                \
   "s_cmp_lt_u32 s84, 0x1000000\n\t"                                   \
-  "s_cbranch_scc1 .Lzh_rn" #N "_%=\n\t"                               \
-  CHK                                                                 \
+  "s_cbranch_scc1 .Lzh_rl" #N "_%=\n\t"
+// ... after the EOS flag (N = 0) or bit N (N = 1..7)
+#define ZH_FAST_RENORM(N)                                             \
+  ".Lzh_rn" #N "_%=:\n\t"                                             \
+  ZH_FAST_SHIFT_IN(N)                                                 \
+  ZH_FAST_CHK                                                         \
+  "s_branch .Lzh_bk" #N "_%=\n\t"
+// ... after the byte's last bit
+#define ZH_FAST_RENORM_LAST(N)                                        \
+  ".Lzh_rn" #N "_%=:\n\t"                                             \
+  ZH_FAST_SHIFT_IN(N)                                                 \
+  ZH_FAST_CHK8                                                        \
   "s_branch .Lzh_bk" #N "_%=\n\t"
 
 #define ZH_FAST_CHK                                                   \
   "s_cmp_lt_u32 %[curr], %[low]\n\t"                                  \
-  "s_cselect_b32 s93, 1, s93\n\t"                                     \
+  "s_cbranch_scc1 .Lzh_corrupt_%=\n\t"                                \
   "s_cmp_gt_u32 %[curr], %[high]\n\t"                                 \
-  "s_cselect_b32 s93, 1, s93\n\t"
+  "s_cbranch_scc1 .Lzh_corrupt_%=\n\t"
 
 // The last bit's renormalisation: a state out of range is not an error of THIS byte (Decoder.cs:138 raises it at the
 // next decode() call), so the byte is still published and the loop is left; the C++ body's EOS test reports it.
@@ -83,8 +104,7 @@
 #define ZH_FAST_EPILOGUE                                              \
   "s_lshl4_add_u32 s92, s90, s91\n\t"                                 \
   "s_add_u32 s92, s92, 0xfffffef0\n\t"                                \
-  "s_lshl_b32 s80, %[t], 21\n\t"                                      \
-  "s_and_b32 s80, s80, 0xfe000000\n\t"                                \
+  "s_lshl_b32 s80, %[t], 25\n\t"                                      \
   "s_lshl_b32 s84, s92, 15\n\t"                                       \
   "s_or_b32 s80, s80, s84\n\t"                                        \
   "s_or_b32 s80, s80, s82\n\t"                                        \
@@ -98,7 +118,7 @@
   "s_lshl_b32 %[h0], s92, %[hs]\n\t"
 
 // s80 scratch   s81 window id   s82 slot   s83 back   s84-s88 step scratch   s89 lag
-// s90 j (16|n1) s91 j2 (16|n2)  s92 byte   s93 bad    s94 probability
+// s90 j (16|n1) s91 j2 (16|n2)  s92 byte   s94 probability
 // v250:v251 four second-nibble probabilities / selected one   v252 scratch
 // v249 first-nibble probabilities << 16 (loaded into the high half: ds_read_u16_d16_hi; its low half stays zero)
 //
@@ -107,7 +127,6 @@
 // y = curr <= low) needs one compare.  zh_cm.hip enters the loop only with the state in range.
 #define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_) \
   asm volatile(                                                       \
-  "s_mov_b32 s93, 0\n\t"                                              \
   "v_mov_b32_e32 v249, 0\n\t"                                         \
   ".p2align 8\n"                                                      \
   ".Lzh_byte_%=:\n\t"                                                 \
@@ -137,13 +156,12 @@
   "s_cmp_le_u32 %[curr], %[low]\n\t"                                  \
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
   "s_add_u32 %[low], %[low], 1\n\t"                                   \
-  "s_mov_b32 s90, 1\n\t"                                              \
   "s_xor_b32 s84, %[high], %[low]\n\t"                                \
   "s_cmp_lt_u32 s84, 0x1000000\n\t"                                   \
   "s_cbranch_scc1 .Lzh_rn0_%=\n"                                      \
   ".Lzh_bk0_%=:\n\t"                                                  \
-  "s_waitcnt lgkmcnt(1)\n\t"                                          \
-  ZH_FAST_STEP("v249", "s90", "s90", 1)                               \
+  "s_waitcnt lgkmcnt(0)\n\t"                                          \
+  ZH_FAST_STEP1("v249", "s90", "1", 1)                               \
   ZH_FAST_STEP("v249", "s90", "s90", 2)                               \
   ZH_FAST_STEP("v249", "s90", "s90", 3)                               \
   ZH_FAST_STEP("v249", "s90", "s90", 4)                               \
@@ -152,20 +170,16 @@
   "s_and_b32 s80, s80, 48\n\t"                                        \
   "s_and_b32 s89, s90, 3\n\t"                                         \
   "s_lshl_b32 s89, s89, 4\n\t"                                        \
-  "s_waitcnt lgkmcnt(0)\n\t"                                          \
   "v_lshrrev_b64 v[250:251], s80, v[250:251]\n\t"                     \
   "v_lshlrev_b32_e32 v250, 16, v250\n\t"                              \
-  "s_mov_b32 s91, 1\n\t"                                              \
-  "s_add_u32 s80, s89, s91\n\t"                                       \
-  ZH_FAST_STEP("v250", "s91", "s80", 5)                               \
+  "s_add_u32 s80, s89, 1\n\t"                                         \
+  ZH_FAST_STEP1("v250", "s91", "s80", 5)                               \
   "s_add_u32 s80, s89, s91\n\t"                                       \
   ZH_FAST_STEP("v250", "s91", "s80", 6)                               \
   "s_add_u32 s80, s89, s91\n\t"                                       \
   ZH_FAST_STEP("v250", "s91", "s80", 7)                               \
   "s_add_u32 s80, s89, s91\n\t"                                       \
   ZH_FAST_STEP("v250", "s91", "s80", 8)                               \
-  "s_cmp_lg_u32 s93, 0\n\t"                                           \
-  "s_cbranch_scc1 .Lzh_corrupt_%=\n\t"                                \
   ZH_FAST_EPILOGUE                                                    \
   "s_branch .Lzh_byte_%=\n"                                           \
   /* ---- out of line ---- */                                         \
@@ -183,18 +197,16 @@
   "s_cmp_lg_u32 s80, 0\n\t"                                           \
   "s_cbranch_scc1 .Lzh_spin_%=\n\t"                                   \
   "s_branch .Lzh_slow_%=\n\t"                                         \
-  ZH_FAST_RENORM(0, ZH_FAST_CHK)                                      \
-  ZH_FAST_RENORM(1, ZH_FAST_CHK)                                      \
-  ZH_FAST_RENORM(2, ZH_FAST_CHK)                                      \
-  ZH_FAST_RENORM(3, ZH_FAST_CHK)                                      \
-  ZH_FAST_RENORM(4, ZH_FAST_CHK)                                      \
-  ZH_FAST_RENORM(5, ZH_FAST_CHK)                                      \
-  ZH_FAST_RENORM(6, ZH_FAST_CHK)                                      \
-  ZH_FAST_RENORM(7, ZH_FAST_CHK)                                      \
-  ZH_FAST_RENORM(8, ZH_FAST_CHK8)                                     \
+  ZH_FAST_RENORM(0)                                                   \
+  ZH_FAST_RENORM(1)                                                   \
+  ZH_FAST_RENORM(2)                                                   \
+  ZH_FAST_RENORM(3)                                                   \
+  ZH_FAST_RENORM(4)                                                   \
+  ZH_FAST_RENORM(5)                                                   \
+  ZH_FAST_RENORM(6)                                                   \
+  ZH_FAST_RENORM(7)                                                   \
+  ZH_FAST_RENORM_LAST(8)                                              \
   ".Lzh_oor_%=:\n\t"                                                  \
-  "s_cmp_lg_u32 s93, 0\n\t"                                           \
-  "s_cbranch_scc1 .Lzh_corrupt_%=\n\t"                                \
   ZH_FAST_EPILOGUE                                                    \
   "s_branch .Lzh_slow_%=\n"                                           \
   ".Lzh_corrupt_%=:\n\t"                                              \
@@ -209,5 +221,5 @@
   : [klim] "s"(klim_), [bfe] "s"(bfe_), [hs] "s"(hs_), [vm] "v"(vm_), [bsa] "v"(bsa_),             \
     [cur] "v"(cur_), [tag] "v"(tag_), [la] "v"(la_), [lb] "v"(lb_)                        \
   : "memory", "scc", "vcc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",   \
-    "s91", "s92", "s93", "s94", "v249", "v250", "v251", "v252")
+    "s91", "s92", "s94", "v249", "v250", "v251", "v252")
 // clang-format on
