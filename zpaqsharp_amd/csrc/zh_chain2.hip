@@ -273,7 +273,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     uint32_t st = 0;                                    // its bit-history state
     uint32_t eA = 0, eB = 0;                            // its value
     int mw[2] = {0, 0};                                 // weight of this lane in the current row of each HBM mixer
-    uint32_t mrow[2] = {0, 0};                          // arena offset of that row (scalar)
+    uint32_t mrow[2] = {0, 0};                          // buffer offset of this lane's weight in that row
     // MATCH (Predictor.cs:273-287, 382-411): the lane's Component fields
     uint32_t m_len = 0, m_ptr = 0, m_limit = 0, m_byte = 0;
     int pm0 = 0, pm1 = 0;                               // stretch of -+dt2k[len] for this byte; 0 once the match has failed
@@ -390,13 +390,17 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     // Mixer rows (Predictor.cs:302-316: row (h[i] + (c8 & mask)) & (size - 1)).  A block comes here only with the model's
     // own COMP list and HCOMP (zh_framing.cpp), whose mixer contexts are multiples of 256 with mask 255: the 255 rows of
     // a byte are consecutive, mx_rb + c8 * row bytes.
-    uint32_t mx_h[2] = {0, 0}, mx_rb[2] = {0, 0};        // h[] of the mixer components, arena offset of their row 0 (scalar)
+    uint32_t mx_h[2] = {0, 0}, mx_rb[2] = {0, 0};        // h[] of the mixer components; this lane's buffer offset in row 0 of the byte
     auto mix_set = [&](uint32_t q, uint32_t hq) __attribute__((always_inline)) {
       mx_h[q] = uni(hq);
-      mx_rb[q] = uni(mx_base[q] + (mx_h[q] & mx_size1[q] & ~255u) * mx_m4[q]);
+      mx_rb[q] = vo_mix[q] + (mx_base[q] + (mx_h[q] & mx_size1[q] & ~255u) * mx_m4[q]);
     };
+    // The row's place is a per-lane buffer offset (lane's weight inside the row + row): all of it vector arithmetic, so that
+    // no value has to cross from the vector to the scalar unit on the way to the load (round 2 kept the row part in an SGPR:
+    // under this kernel's scalar-register pressure the compiler held its operands in VGPRs anyway and paid a
+    // v_readfirstlane, ~24 cycles, in front of every bit's loads).  Lanes that do not feed the mixer stay out of range.
     auto mix_row = [&](uint32_t q, uint32_t c8) __attribute__((always_inline)) -> uint32_t {
-      return uni(mx_rb[q] + (c8 & 255u) * (SP::mix_m[q] * 4u));          // pinned to the scalar unit
+      return mx_rb[q] + (c8 & 255u) * (SP::mix_m[q] * 4u);
     };
     // ---- tail of the max model (components 17-21); the host routes a block here only with the built-in HCOMP, which
     // leaves h[17] = h[18] = h[19] = h[21] = 0 and h[20] = byte << 9 (even), so the two rows a bit can lead to are one
@@ -441,7 +445,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
         for (uint32_t q = 0; q < SP::nmix; ++q) {
           mix_set(q, 0u);
           mrow[q] = mix_row(q, 1u);
-          mw[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow[q], 0);
+          mw[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, mrow[q], 0, 0);
         }
         if (SP::has_tail) { row18 = row18_load(1u); row20 = row20_load(1u); a19i = 1u; w19 = uni((uint32_t)S.a19[1]); }
       }
@@ -496,10 +500,10 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             if (pre_mx) {
 #pragma unroll
               for (uint32_t q = 0; q < SP::nmix; ++q) {
-                mrow0[q] = mix_row(q, c8 * 2u);
+                mrow0[q] = mx_rb[q] + (c8 * 2u) * (SP::mix_m[q] * 4u);      // (c8 < 128 here: no mask)
                 mrow1[q] = mrow0[q] + SP::mix_m[q] * 4u;
-                mwc0[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow0[q], 0);
-                mwc1[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow1[q], 0);
+                mwc0[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, mrow0[q], 0, 0);
+                mwc1[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, mrow1[q], 0, 0);
               }
             }
             uint32_t row18n = 0, row20n = 0, w19n0 = 0, w19n1 = 0;
@@ -608,7 +612,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             for (uint32_t q = 0; q < SP::nmix; ++q) {     // MIX (Predictor.cs:427-439): error from the mixer lane
               const int eq = __mul24((int)rdlane((uint32_t)e, SP::mix_lane[q]), mx_rate[q]) >> 4;
               const int nmw = med3i(mw[q] + ((__mul24(eq, p) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
-              __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw, rsrc, vo_mix[q], uni(mrow[q]), 0);
+              __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw, rsrc, mrow[q], 0, 0);
             }
             if constexpr (SP::id == 3) {
               auto mix2_train = [&](int w, int rate, uint32_t ln, int pj_, int pk_) __attribute__((always_inline)) -> int {   // Predictor.cs:414-426
@@ -646,7 +650,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             c8 = c8 * 2u + y;
             if (pre_mx) {
 #pragma unroll
-              for (uint32_t q = 0; q < SP::nmix; ++q) { mw[q] = y ? mwc1[q] : mwc0[q]; mrow[q] = uni(y ? mrow1[q] : mrow0[q]); }
+              for (uint32_t q = 0; q < SP::nmix; ++q) { mw[q] = y ? mwc1[q] : mwc0[q]; mrow[q] = y ? mrow1[q] : mrow0[q]; }
             }
             if (SP::has_tail && pre_mx) {
               row18 = row18n; row20 = row20n;
@@ -766,7 +770,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             for (uint32_t q = 0; q < SP::nmix; ++q) {
               mix_set(q, rdlane(hv, SP::mix_lane[q]));
               mrow[q] = mix_row(q, 1u);
-              mw[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_mix[q], mrow[q], 0);
+              mw[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, mrow[q], 0, 0);
             }
             if (SP::has_tail) {
               t_h20 = rdlane(hv, 20);
