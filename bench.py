@@ -52,10 +52,11 @@ CLOCK_GHZ = 2.4                 # max shader clock (same guide)
 
 
 def source_hash():
-    """Identifies the kernels a PMC summary was taken with: SHA-1 over the sources of libzpaqhip."""
+    """Identifies the kernels a PMC summary or an instruction count was taken with: SHA-1 over the device sources of
+    libzpaqhip (zpaqsharp_amd/csrc/*.hip and the headers they include; host-only *.cpp files do not change a kernel)."""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "zpaqsharp_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.cpp"))):
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

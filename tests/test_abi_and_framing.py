@@ -151,3 +151,23 @@ def test_scan_hands_back_the_blocks_before_framing_damage():
     assert d.find_filename() is None and d.find_block() is not None and d.find_filename() is not None
     with pytest.raises(oracle.OracleError, match="missing reserved byte"):
         d.read_comment()
+
+
+def test_committed_instruction_counts_belong_to_these_kernel_sources(tmp_path):
+    """bench.py quotes profiles/<round>/instr_<kernel>.json only when it was counted on the device sources it runs with;
+    the newest committed count of every hot kernel must be current (re-run `python tools/count_instr.py` after a kernel
+    change: no GPU needed) and must be what the tool finds in the built library."""
+    import glob
+    import json
+    import subprocess
+    import sys
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "count_instr.py"), "--out", str(tmp_path)], check=True,
+                   stdout=subprocess.DEVNULL)
+    for model, sym in bench.INSTR_KERNEL.items():
+        n, src = bench.decoder_instr_per_byte(model)
+        assert n is not None, (sym, src)
+        fresh = json.load(open(os.path.join(str(tmp_path), f"instr_{sym}.json")))
+        assert fresh["instr_per_byte_static"] == n and fresh["src_hash"] == bench.source_hash()
+        assert 100 <= n <= 4000

@@ -44,7 +44,7 @@ namespace {
 // Diagnostic build (PROF): cycles per stage, summed per block into L.debug[0..7].  Stamps wait for LDS/scalar results
 // only (global memory stays in flight, as in the real kernel).
 #ifndef C2_PROF_MASK
-#define C2_PROF_MASK 0x1fff                     /* stages the *_prof kernels stamp (fewer stamps: less distortion) */
+#define C2_PROF_MASK 0x0fff                     /* stages the *_prof kernels stamp (fewer stamps: less distortion) */
 #endif
 #define C2_STAMP(i)                                                                                  \
   do {                                                                                               \
