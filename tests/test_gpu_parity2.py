@@ -548,3 +548,20 @@ def test_cost_weighted_plan_balances_kernel_time_on_an_archive_that_mixes_models
     assert abs(k[0] - k[1]) / max(k) < 0.10, k
     k_old = run(multigpu.lpt_assign(coded, 2))
     print("kernel ms per rank: cost-weighted plan", k, "coded-bytes plan", k_old)
+
+
+def test_kernel_families_side_by_side_and_one_after_the_other_agree(ctx):
+    """A batch whose blocks need several kernels (l1, min, mid, max, stored) runs them on forked streams with one arena
+    region each; ZPAQHIP_SERIAL_FAMILIES=1 is the round-2 order (one family after the other in one region).  Same
+    results either way, every segment's SHA-1 verified."""
+    s, want = _mixed_stream(n_blocks=31, seed=21)
+    extra = [util.text(30000, seed=400 + i) for i in range(4)]
+    s2 = s + b"".join(util.block(m, d) for m, d in zip(("max", "mid", "max", "l1"), extra))
+    want2 = want + b"".join(extra)
+    got = ctx.decompress(s2, verify_sha1=True).tobytes()
+    assert got == want2 and ctx.stats().launches >= 5
+    os.environ["ZPAQHIP_SERIAL_FAMILIES"] = "1"
+    try:
+        assert ctx.decompress(s2, verify_sha1=True).tobytes() == want2
+    finally:
+        del os.environ["ZPAQHIP_SERIAL_FAMILIES"]

@@ -67,6 +67,11 @@ struct zpaqhip_ctx {
   uint8_t *pin[2] = {nullptr, nullptr};
   zpaqhip_stats stats{};
   uint32_t mem_share = 1;                 // contexts of this process that share the device (zpaqhip_decompress_multi): divides the memory budgets
+  // a launch whose blocks need several kernel families (an archive that mixes models): one stream per family, forked from
+  // and joined to the launch stream, each family with its own region of the arena
+  hipStream_t fam_stream[ZH_NFAM] = {};
+  hipEvent_t fam_ev[ZH_NFAM] = {};
+  hipEvent_t fork_ev = nullptr;
   std::vector<uint32_t> raw_pp;           // last decode: per segment pp_state | PCOMP length << 8, as the kernels report it
 };
 
@@ -155,6 +160,11 @@ void zpaqhip_ctx_destroy(zpaqhip_ctx *c) {
   if (c->ev_h1) (void)hipEventDestroy(c->ev_h1);
   if (c->s_in) (void)hipStreamDestroy(c->s_in);
   if (c->s_out) (void)hipStreamDestroy(c->s_out);
+  for (uint32_t g = 0; g < ZH_NFAM; ++g) {
+    if (c->fam_ev[g]) (void)hipEventDestroy(c->fam_ev[g]);
+    if (c->fam_stream[g]) (void)hipStreamDestroy(c->fam_stream[g]);
+  }
+  if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -331,9 +341,12 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
   HIPCHK(hipMemsetAsync(c->results.p, 0xff, n_segs * sizeof(ZhSegResult), stream));
   HIPCHK(hipMemsetAsync(c->queue.p, 0, kQueueBytes + kDebugBytes, stream));
 
-  // arena: sized for the most demanding group
+  // arena: one region per kernel family when all of them fit at once (the families then run side by side: an archive
+  // that mixes models fills the GPU with whatever blocks it has), else one region sized for the most demanding family,
+  // used by one family after the other
   uint32_t slots_of[ZH_NFAM] = {};
-  uint64_t stride_of[ZH_NFAM], arena_need = 0;
+  uint64_t stride_of[ZH_NFAM], arena_need = 0, arena_sum = 0, arena_off[ZH_NFAM] = {};
+  uint32_t n_fam = 0;
   for (auto &x : stride_of) x = 256;
   for (uint32_t g = 0; g < ZH_NFAM; ++g) {
     if (groups[g].empty()) continue;
@@ -343,8 +356,14 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     uint32_t want = opts.max_concurrent ? opts.max_concurrent : 256u;   // one wave per CU by default
     slots_of[g] = (uint32_t)std::min<uint64_t>({(uint64_t)want, max_slots, (uint64_t)groups[g].size()});
     arena_need = std::max<uint64_t>(arena_need, slots_of[g] * stride_of[g]);
+    arena_off[g] = arena_sum;
+    arena_sum += (slots_of[g] * stride_of[g] + 255) & ~255ull;
+    ++n_fam;
   }
-  HIPCHK(c->arena.reserve((size_t)arena_need));
+  const bool side_by_side = n_fam > 1 && arena_sum <= mem_budget && !getenv("ZPAQHIP_SERIAL_FAMILIES");
+  if (!side_by_side) for (auto &x : arena_off) x = 0;
+  HIPCHK(c->arena.reserve((size_t)(side_by_side ? arena_sum : arena_need)));
+  if (side_by_side && !c->fork_ev) HIPCHK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
 
   std::vector<ZhBlockDesc> &bd_sorted = P.bd_sorted;
   bd_sorted.reserve(sel.size());
@@ -359,8 +378,19 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
 
   uint32_t launches = 0, slots = 0, kind_used = 0;
   HIPCHK(hipEventRecord(c->ev0, stream));
+  if (side_by_side) HIPCHK(hipEventRecord(c->fork_ev, stream));      // the tables and descriptors above are on `stream`
+  hipStream_t const launch_stream = stream;
   for (uint32_t g = 0; g < ZH_NFAM; ++g) {
     if (groups[g].empty()) continue;
+    hipStream_t stream = launch_stream;                  // (shadows: the family's own stream when families run side by side)
+    if (side_by_side) {
+      if (!c->fam_stream[g]) {
+        HIPCHK(hipStreamCreateWithFlags(&c->fam_stream[g], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->fam_ev[g], hipEventDisableTiming));
+      }
+      stream = c->fam_stream[g];
+      HIPCHK(hipStreamWaitEvent(stream, c->fork_ev, 0));
+    }
     ZhLaunch L;
     memset(&L, 0, sizeof L);
     L.in = (const uint8_t *)d_in;
@@ -371,7 +401,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     L.segs = (const ZhSegDesc *)c->sdesc.p;
     L.results = (ZhSegResult *)c->results.p;
     L.out = (uint8_t *)d_out;
-    L.arena = (uint8_t *)c->arena.p;
+    L.arena = (uint8_t *)c->arena.p + arena_off[g];
     L.arena_stride = stride_of[g];
     L.tables = (const ZhTables *)c->tables.p;
     L.queue = (uint32_t *)c->queue.p + 8 * g;           // one work-queue head per launch
@@ -396,6 +426,10 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
       HIPCHK(zh_launch_chain(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof, pcall));
     }
     else HIPCHK(zh_launch_generic(&L, slots_of[g], stream));
+    if (side_by_side) {                                  // join: the launch stream goes on when every family is done
+      HIPCHK(hipEventRecord(c->fam_ev[g], stream));
+      HIPCHK(hipStreamWaitEvent(launch_stream, c->fam_ev[g], 0));
+    }
     ++launches;
     slots = std::max(slots, slots_of[g]);
     kind_used = std::max(kind_used, g == ZH_FAM_STORE ? 1u : std::min(g, (uint32_t)ZH_FAM_CHAIN) + 1);
