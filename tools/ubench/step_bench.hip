@@ -194,6 +194,22 @@ __global__ void k(uint64_t *out, uint32_t seed, int spin) {
   STAMP(t0);
   asm volatile(REP16("s_cmp_le_u32 %[j], %[h]\n\ts_cselect_b32 %[j], %[h], %[j]\n\t") : [j] "+s"(j) : [h] "s"(high) : "scc");
   STAMP(t1); out[n++] = t1 - t0;       // cmp -> cselect x16
+  {  // VALU -> SGPR -> VALU: v_readlane feeding a vector instruction through its scalar operand (no SALU in between)
+    uint32_t vv = pv;
+    STAMP(t0);
+    asm volatile(REP16("v_readlane_b32 s94, %[v], 7\n\tv_add_u32_e32 %[v], s94, %[v]\n\tv_xor_b32_e32 %[v], 0x55, %[v]\n\t") : [v] "+v"(vv) : : "s94");
+    STAMP(t1); out[n++] = t1 - t0;     // readlane -> valu(sgpr operand) -> valu, x16
+    STAMP(t0);
+    asm volatile(REP16("v_readfirstlane_b32 s94, %[v]\n\ts_add_u32 s94, s94, 3\n\tv_add_u32_e32 %[v], s94, %[v]\n\t") : [v] "+v"(vv) : : "s94", "scc");
+    STAMP(t1); out[n++] = t1 - t0;     // readfirstlane -> salu -> valu(sgpr operand), x16
+    STAMP(t0);
+    asm volatile(REP16("v_add_u32_e32 %[v], 3, %[v]\n\tv_xor_b32_e32 %[v], 0x55, %[v]\n\tv_mul_u32_u24_e32 %[v], 3, %[v]\n\t") : [v] "+v"(vv));
+    STAMP(t1); out[n++] = t1 - t0;     // three dependent valu, x16
+    STAMP(t0);
+    asm volatile(REP16("ds_bpermute_b32 %[v], %[v], %[v]\n\ts_waitcnt lgkmcnt(0)\n\tv_and_b32_e32 %[v], 0xfc, %[v]\n\t") : [v] "+v"(vv) : : "memory");
+    STAMP(t1); out[n++] = t1 - t0;     // ds_bpermute -> wait -> valu, x16
+    curr += vv;
+  }
   STAMP(t0);
   STAMP(t1); out[n++] = t1 - t0;
   out[n++] = low + high + curr + j;
@@ -204,7 +220,7 @@ int main() {
   uint64_t *d;
   hipMalloc(&d, 256);
   const char *names[] = {"STEP x16 (cold)", "STEP x16", "STEP2 x16 (cold)", "STEP2 x16", "4 nibbles, readlane per step (cold)", "4 nibbles, readlane per step", "4 nibbles, children pairs (cold)", "4 nibbles, children pairs", "4 nibbles, early fetch (cold)", "4 nibbles, early fetch", "4 nibbles, exec + readfirstlane (cold)", "4 nibbles, exec + readfirstlane", "4 nibbles, 15 nodes in SGPRs (cold)", "4 nibbles, 15 nodes in SGPRs", "readlane->2 salu x16 (48)", "mul_hi->add x16 (32)",
-                         "cmp->cselect x16 (32)", "empty stamp pair"};
+                         "cmp->cselect x16 (32)", "readlane->valu(sgpr)->valu x16 (48)", "readfirstlane->salu->valu x16 (48)", "3 dependent valu x16 (48)", "ds_bpermute->wait->valu x16", "empty stamp pair"};
   for (int spin = 0; spin < 2; ++spin) {
     for (int rep = 0; rep < 2; ++rep) {
       hipLaunchKernelGGL(k, dim3(1), dim3(128), 0, 0, d, 12345u, spin);
@@ -213,7 +229,7 @@ int main() {
     uint64_t o[32];
     hipMemcpy(o, d, 256, hipMemcpyDeviceToHost);
     printf("second wave: %s\n", spin == 0 ? "exits at once" : spin == 1 ? "polls LDS flat out" : "polls LDS with s_sleep 2");
-    for (int i = 0; i < 18; ++i) printf("  %-32s %6llu cycles\n", names[i], (unsigned long long)o[i]);
+    for (int i = 0; i < 22; ++i) printf("  %-32s %6llu cycles\n", names[i], (unsigned long long)o[i]);
   }
   return 0;
 }
