@@ -393,32 +393,29 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     uint32_t mx_h[2] = {0, 0}, mx_rb[2] = {0, 0};        // h[] of the mixer components; this lane's buffer offset in row 0 of the byte
     auto mix_set = [&](uint32_t q, uint32_t hq) __attribute__((always_inline)) {
       mx_h[q] = uni(hq);
-      mx_rb[q] = vo_mix[q] + (mx_base[q] + (mx_h[q] & mx_size1[q] & ~255u) * mx_m4[q]);
+      mx_rb[q] = vo_mix[q] + (mx_base[q] + __umul24(mx_h[q] & mx_size1[q] & ~255u, mx_m4[q]));   // < 2^16 x < 2^8: 24-bit multiplies are full rate
     };
     // The row's place is a per-lane buffer offset (lane's weight inside the row + row): all of it vector arithmetic, so that
     // no value has to cross from the vector to the scalar unit on the way to the load (round 2 kept the row part in an SGPR:
     // under this kernel's scalar-register pressure the compiler held its operands in VGPRs anyway and paid a
     // v_readfirstlane, ~24 cycles, in front of every bit's loads).  Lanes that do not feed the mixer stay out of range.
     auto mix_row = [&](uint32_t q, uint32_t c8) __attribute__((always_inline)) -> uint32_t {
-      return mx_rb[q] + (c8 & 255u) * (SP::mix_m[q] * 4u);
+      return mx_rb[q] + __umul24(c8 & 255u, SP::mix_m[q] * 4u);
     };
     // ---- tail of the max model (components 17-21); the host routes a block here only with the built-in HCOMP, which
     // leaves h[17] = h[18] = h[19] = h[21] = 0 and h[20] = byte << 9 (even), so the two rows a bit can lead to are one
     // aligned row pair of each SSE table
     int w17 = 32768, w21 = 32768;                        // mix2 with a single weight (sizebits 0): kept in registers
     uint32_t w19 = 32768, a19i = 0;                      // mix2 19: current weight and its index in S.a19
-    uint32_t row18 = 0, row20 = 0;                       // per lane: entry (lane & 31) of row 2r + (lane >> 5) of the SSE tables
+    uint32_t row20 = 0;                                  // per lane: entry (lane & 31) of row 2r + (lane >> 5) of `sse 16 19` (HBM)
     uint32_t t_h20 = 0;
     const uint32_t sse20_base = SP::has_tail ? uni((uint32_t)M->comp[20].cm_off) : 0u, sse20_mask = SP::has_tail ? uni(M->comp[20].cm_mask) : 0u;
-    auto row18_load = [&](uint32_t c8x) __attribute__((always_inline)) -> uint32_t {     // rows (c8x & ~1), +1 of the LDS table
-      return *(lds_u32_p)(lds_off(S.sse18) + ((c8x & 254u) * 128u) + lane * 4u);
-    };
     auto row20_load = [&](uint32_t c8x) __attribute__((always_inline)) -> uint32_t {
-      const uint32_t r = uni((((t_h20 + (c8x & ~1u)) * 32u) & sse20_mask) * 4u + sse20_base);
-      return __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4u, r, 0);
+      const uint32_t r = (((t_h20 + (c8x & ~1u)) * 32u) & sse20_mask) * 4u + sse20_base;   // (a per-lane offset: no scalar round trip, see mix_row)
+      return __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4u + r, 0, 0);
     };
-    auto stretch_u = [&](uint32_t ix) __attribute__((always_inline)) -> int {             // stretch() of a wave-uniform argument
-      return (int)uni((uint32_t)(int)*(lds_i16_p)((uint32_t)(uintptr_t)lds_stretch + ix * 2u));
+    auto stretch_u = [&](uint32_t ix) __attribute__((always_inline)) -> int {             // stretch() of a wave-uniform argument (stays a vector value)
+      return (int)*(lds_i16_p)((uint32_t)(uintptr_t)lds_stretch + ix * 2u);
     };
 
     int failed = 0;
@@ -447,7 +444,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
           mrow[q] = mix_row(q, 1u);
           mw[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, mrow[q], 0, 0);
         }
-        if (SP::has_tail) { row18 = row18_load(1u); row20 = row20_load(1u); a19i = 1u; w19 = uni((uint32_t)S.a19[1]); }
+        if (SP::has_tail) { row20 = row20_load(1u); a19i = 1u; w19 = uni((uint32_t)S.a19[1]); }
       }
 
       for (;;) {                                       // one decoded byte per iteration
@@ -500,18 +497,19 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             if (pre_mx) {
 #pragma unroll
               for (uint32_t q = 0; q < SP::nmix; ++q) {
-                mrow0[q] = mx_rb[q] + (c8 * 2u) * (SP::mix_m[q] * 4u);      // (c8 < 128 here: no mask)
+                // c8 < 128 here (no mask); v_mad_u32_u24 by hand: the compiler turns this into v_mad_u64_u32, a quarter-rate
+                // instruction, whatever the source says about the operands' width
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(mrow0[q]) : "s"(c8), "v"(SP::mix_m[q] * 8u), "v"(mx_rb[q]));
                 mrow1[q] = mrow0[q] + SP::mix_m[q] * 4u;
                 mwc0[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, mrow0[q], 0, 0);
                 mwc1[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, mrow1[q], 0, 0);
               }
             }
-            uint32_t row18n = 0, row20n = 0, w19n0 = 0, w19n1 = 0;
+            uint32_t row20n = 0, w19n0 = 0, w19n1 = 0;
             if (SP::has_tail && pre_mx) {
-              row18n = row18_load(c8 * 2u);
               row20n = row20_load(c8 * 2u);
               const uint32_t wp = *(lds_u32_p)(lds_off(S.a19) + ((c8 * 2u) & 254u) * 2u);       // entries 2c8, 2c8+1
-              w19n0 = uni(wp) & 0xffffu; w19n1 = uni(wp) >> 16;
+              w19n0 = wp & 0xffffu; w19n1 = wp >> 16;       // (stay on the vector unit: every reader is a vector instruction)
             }
             // ---- (b) predict: operands of the systolic ISSE step
             int xs = pself;
@@ -548,23 +546,36 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               t0 += dpp_shr(t0, 8); t1 += dpp_shr(t1, 8);
               p15 = med3i((int)rdlane((uint32_t)t0, 15) >> 8, -2048, 2047);
               p = lane == 15u ? p15 : p;
-              p16 = med3i(((int)rdlane((uint32_t)t1, 15) + (int)rdlane((uint32_t)w1hi, 15) * p15) >> 8, -2048, 2047);
-              p17 = (w17 * p15 + (65536 - w17) * p16) >> 16;                 // MIX2 17 (Predictor.cs:291-301)
+              p16 = med3i(((int)rdlane((uint32_t)t1, 15) + __mul24((int)rdlane((uint32_t)w1hi, 15), p15)) >> 8, -2048, 2047);
+              // (weights < 2^17, predictions < 2^12, SSE entries >> 10 < 2^22, errors < 2^16: every product of this tail is exact
+              // in 24-bit multiplies, which are full rate where v_mul_lo_u32 is quarter rate)
+              p17 = (__mul24(w17, p15) + __mul24(65536 - w17, p16)) >> 16;   // MIX2 17 (Predictor.cs:291-301)
               auto sse = [&](int pin, uint32_t rowv, int &pout, uint32_t &sel, uint32_t &ti, int &dtv) __attribute__((always_inline)) {   // dtv: per-lane copy, made scalar in update()
                 int pq = pin + 992;                                          // SSE (Predictor.cs:327-340)
                 pq = pq < 0 ? 0 : pq > 1983 ? 1983 : pq;
                 const uint32_t wt = (uint32_t)pq & 63u, iq = (uint32_t)pq >> 6;
                 const uint32_t lo = (c8 & 1u) * 32u + iq;                    // this bit's row is the (c8 & 1) half of the pair
                 const uint32_t e0 = rdlane(rowv, lo), e1 = rdlane(rowv, lo + 1u);
-                pout = stretch_u(((e0 >> 10) * (64u - wt) + (e1 >> 10) * wt) >> 13);
+                pout = stretch_u((__umul24(e0 >> 10, 64u - wt) + __umul24(e1 >> 10, wt)) >> 13);
                 sel = (wt >> 5) ? e1 : e0;                                   // the entry train() will update
                 ti = iq + (wt >> 5);
                 dtv = S.dt[sel & 0x3ffu];                                    // wanted only after the bit is known
               };
-              sse(p17, row18, p18, sel18, ti18, dtv18);
-              p19 = (int)((int)w19 * p17 + (65536 - (int)w19) * p18) >> 16;  // MIX2 19
+              {  // SSE 18 lives in LDS: its two entries are read where they are needed (one ds_read2 by a vector address — no
+                 // row held in a register, no lane select that has to go through the scalar unit)
+                int pq = p17 + 992;
+                pq = pq < 0 ? 0 : pq > 1983 ? 1983 : pq;
+                const uint32_t wt = (uint32_t)pq & 63u, iq = (uint32_t)pq >> 6;                 // iq <= 30
+                const uint32_t ea18 = lds_off(S.sse18) + ((c8 & 255u) * 32u + iq) * 4u;
+                const uint32_t e0 = *(lds_u32_p)ea18, e1 = *(lds_u32_p)(ea18 + 4u);
+                p18 = (int)*(lds_i16_p)((uint32_t)(uintptr_t)lds_stretch + ((__umul24(e0 >> 10, 64u - wt) + __umul24(e1 >> 10, wt)) >> 13) * 2u);
+                sel18 = (wt >> 5) ? e1 : e0;
+                ti18 = iq + (wt >> 5);
+                dtv18 = S.dt[sel18 & 0x3ffu];
+              }
+              p19 = (__mul24((int)w19, p17) + __mul24(65536 - (int)w19, p18)) >> 16;  // MIX2 19
               sse(p19, row20, p20, sel20, ti20, dtv20);
-              const int p21 = (w21 * p19 + (65536 - w21) * p20) >> 16;       // MIX2 21
+              const int p21 = (__mul24(w21, p19) + __mul24(65536 - w21, p20)) >> 16;   // MIX2 21
               p = lane == 16u ? p16 : p;
               p = lane == 17u ? p17 : p;
               p = lane == 19u ? p19 : p;
@@ -616,14 +627,14 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             }
             if constexpr (SP::id == 3) {
               auto mix2_train = [&](int w, int rate, uint32_t ln, int pj_, int pk_) __attribute__((always_inline)) -> int {   // Predictor.cs:414-426
-                const int er = ((int)rdlane((uint32_t)e, ln) * rate) >> 5;
-                w += (er * (pj_ - pk_) + (1 << 12)) >> 13;
+                const int er = __mul24((int)rdlane((uint32_t)e, ln), rate) >> 5;
+                w += (__mul24(er, pj_ - pk_) + (1 << 12)) >> 13;
                 return w < 0 ? 0 : w > 65535 ? 65535 : w;
               };
               auto sse_train = [&](uint32_t pn, int dtv) __attribute__((always_inline)) -> uint32_t {                      // Predictor.train, :1031-1036 form
                 const uint32_t count = pn & 0x3ffu;
                 const int error = ey - (int)(pn >> 17);
-                return pn + (((uint32_t)error * uni((uint32_t)dtv)) & 0xFFFFFC00u) + (count < C2Max::sse_limit);
+                return pn + ((uint32_t)__mul24(error, dtv) & 0xFFFFFC00u) + (count < C2Max::sse_limit);   // |error| < 2^15, dt < 2^16: the low 32 bits are the reference's wrapping product
               };
               w17 = mix2_train(w17, C2Max::rate17, 17, p15, p16);
               const uint32_t n18 = sse_train(sel18, dtv18);
@@ -632,8 +643,8 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               *(lds_u16_p)(lds_off(S.a19) + a19i * 2u) = (uint16_t)w19;
               const uint32_t n20 = sse_train(sel20, dtv20);
               {
-                const uint32_t off = uni(((((t_h20 + c8) * 32u + ti20) & sse20_mask) * 4u) + sse20_base);
-                __builtin_amdgcn_raw_buffer_store_b32(n20, rsrc, lane == 0 ? 0u : kOob, off, 0);
+                const uint32_t off = ((((t_h20 + c8) * 32u + ti20) & sse20_mask) * 4u) + sse20_base;
+                __builtin_amdgcn_raw_buffer_store_b32(n20, rsrc, lane == 0 ? off : kOob, 0, 0);
               }
               w21 = mix2_train(w21, C2Max::rate21, 21, p19, p20);
             }
@@ -653,7 +664,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               for (uint32_t q = 0; q < SP::nmix; ++q) { mw[q] = y ? mwc1[q] : mwc0[q]; mrow[q] = y ? mrow1[q] : mrow0[q]; }
             }
             if (SP::has_tail && pre_mx) {
-              row18 = row18n; row20 = row20n;
+              row20 = row20n;
               w19 = y ? w19n1 : w19n0; a19i = c8 & 255u;
             }
             if (pre_ii) {
@@ -774,7 +785,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             }
             if (SP::has_tail) {
               t_h20 = rdlane(hv, 20);
-              row18 = row18_load(1u); row20 = row20_load(1u);
+              row20 = row20_load(1u);
               a19i = 1u; w19 = uni((uint32_t)S.a19[1]);
             }
             if (SP::match_lane >= 0) {
