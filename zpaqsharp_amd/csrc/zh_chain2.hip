@@ -59,6 +59,13 @@ namespace {
   } while (0)
 
 __device__ __forceinline__ void c2_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }   // one wave: no barrier
+// scalar x vector 24-bit multiply, by hand: where the compiler can prove that a 24-bit multiply equals the 32-bit one it
+// selects v_mul_lo_u32 for an SGPR x VGPR product — a quarter-rate instruction
+__device__ __forceinline__ int mul24_sv(int sc, int vec) {
+  int r;
+  asm("v_mul_i32_i24_e32 %0, %1, %2" : "=v"(r) : "s"(sc), "v"(vec));
+  return r;
+}
 
 template <class SP, bool PROF, int HELP, class LDS>
 __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
@@ -202,6 +209,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
       mx_size1[q] = uni(mc.cm_mask);                      // contexts - 1
       mx_cmask[q] = uni((uint32_t)mc.arg[4]);
       mx_rate[q] = (int)uni((uint32_t)mc.arg[3]);
+      asm volatile("" : "+v"(mx_rate[q]));           // held in a VGPR: the error scaling below stays on the vector unit
       if (lane >= SP::mix_j0[q] && lane < SP::mix_j0[q] + SP::mix_m[q]) vo_mix[q] = (lane - SP::mix_j0[q]) * 4u;
     }
 
@@ -544,9 +552,11 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               t0 += dpp_shr(t0, 2); t1 += dpp_shr(t1, 2);
               t0 += dpp_shr(t0, 4); t1 += dpp_shr(t1, 4);
               t0 += dpp_shr(t0, 8); t1 += dpp_shr(t1, 8);
-              p15 = med3i((int)rdlane((uint32_t)t0, 15) >> 8, -2048, 2047);
+              // (shift before the v_readlane, clamp after it as a vector instruction taking the SGPR: a scalar instruction
+              // between a v_readlane and the vector code that follows costs two hand-overs, ~20 cycles, tools/ubench/step_bench)
+              p15 = med3i((int)rdlane((uint32_t)(t0 >> 8), 15), -2048, 2047);
               p = lane == 15u ? p15 : p;
-              p16 = med3i(((int)rdlane((uint32_t)t1, 15) + __mul24((int)rdlane((uint32_t)w1hi, 15), p15)) >> 8, -2048, 2047);
+              p16 = med3i(((int)rdlane((uint32_t)t1, 15) + mul24_sv((int)rdlane((uint32_t)w1hi, 15), p15)) >> 8, -2048, 2047);
               // (weights < 2^17, predictions < 2^12, SSE entries >> 10 < 2^22, errors < 2^16: every product of this tail is exact
               // in 24-bit multiplies, which are full rate where v_mul_lo_u32 is quarter rate)
               p17 = (__mul24(w17, p15) + __mul24(65536 - w17, p16)) >> 16;   // MIX2 17 (Predictor.cs:291-301)
@@ -593,11 +603,17 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             // squash(p), wanted by the update only, follows from LDS under the decoder's shadow (measured: mid +1.4 %, min -2 %)
             uint32_t ps;
             if (SP::smem_ps) {
-              const uint32_t pso = (rdlane((uint32_t)p, SP::final_lane) + 2048u) << 2;
+              uint32_t pv4 = ((uint32_t)p << 2) + 8192u;       // (p + 2048) * 4, scaled on the vector side: the v_readlane feeds the s_load directly
+              asm("" : "+v"(pv4));                             // (the compiler would move the arithmetic behind the v_readlane, onto the scalar unit)
+              const uint32_t pso = rdlane(pv4, SP::final_lane);
               asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(ps) : "s"(ps_tab), "s"(pso));
             }
             const int sqp = (int)*(lds_u16_p)((uint32_t)(uintptr_t)lds_squash + (uint32_t)(p + 2048) * 2u);
-            if (!SP::smem_ps) ps = (rdlane((uint32_t)sqp, SP::final_lane) * 2 + 1) << 16;
+            if (!SP::smem_ps && SP::id == 3) {           // (squash * 2 + 1) << 16 on the vector side (max +0.3 %; min -0.3 %: not there)
+              uint32_t psv = ((uint32_t)sqp << 17) | 0x10000u;
+              asm("" : "+v"(psv));
+              ps = rdlane(psv, SP::final_lane);
+            } else if (!SP::smem_ps) ps = (rdlane((uint32_t)sqp, SP::final_lane) * 2 + 1) << 16;
             uint32_t jb = j, xr;
             ZH_DEC_STEP_LITE(d, ps, jb, xr);
             j = jb;
@@ -621,13 +637,15 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             const int nw1 = med3i((int)eB + ((e + 16) >> 5), -(1 << 19), (1 << 19) - 1);
 #pragma unroll
             for (uint32_t q = 0; q < SP::nmix; ++q) {     // MIX (Predictor.cs:427-439): error from the mixer lane
-              const int eq = __mul24((int)rdlane((uint32_t)e, SP::mix_lane[q]), mx_rate[q]) >> 4;
+              const int eq = mul24_sv((int)rdlane((uint32_t)e, SP::mix_lane[q]), mx_rate[q]) >> 4;
               const int nmw = med3i(mw[q] + ((__mul24(eq, p) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
               __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw, rsrc, mrow[q], 0, 0);
             }
             if constexpr (SP::id == 3) {
               auto mix2_train = [&](int w, int rate, uint32_t ln, int pj_, int pk_) __attribute__((always_inline)) -> int {   // Predictor.cs:414-426
-                const int er = __mul24((int)rdlane((uint32_t)e, ln), rate) >> 5;
+                int vrate = rate;
+                asm volatile("" : "+v"(vrate));
+                const int er = mul24_sv((int)rdlane((uint32_t)e, ln), vrate) >> 5;
                 w += (__mul24(er, pj_ - pk_) + (1 << 12)) >> 13;
                 return w < 0 ? 0 : w > 65535 ? 65535 : w;
               };
