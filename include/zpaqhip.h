@@ -212,8 +212,8 @@ int zpaqhip_decompress_multi_stats(const int *devices, size_t n_devices, const u
                                    const zpaqhip_opts *opts, zpaqhip_stats *per_device, zpaqhip_err *err);
 
 /* Estimated decode cost of each block of a scanned stream, the weight every multi-GPU plan here uses: plaintext bytes
- * (the comment's decimal size when plausible, else 4 x coded bytes) x the instructions per plaintext byte of the kernel
- * the block's header selects.  Decode time of a block is its bit count times the depth of its model
+ * (the comment's decimal size when plausible, else 4 x coded bytes) x the cycles per plaintext byte of the kernel
+ * the block's header selects (measured).  Decode time of a block is its bit count times the depth of its model
  * (Predictor.cs:245-475 runs once per bit), not its coded size.  Host-side, no GPU needed. */
 int zpaqhip_block_costs(const uint8_t *in, size_t in_len, const zpaqhip_block *blocks, size_t n_blocks,
                         const zpaqhip_segment *segs, size_t n_segs, uint64_t *cost, zpaqhip_err *err);

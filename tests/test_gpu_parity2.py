@@ -511,7 +511,7 @@ def test_multi_device_queue_on_an_archive_that_mixes_models(ctx):
 
 
 def test_cost_weighted_plan_balances_kernel_time_on_an_archive_that_mixes_models(ctx):
-    """The weights of the multi-GPU plan (zpaqhip_block_costs: plaintext bytes x instructions per byte of the block's
+    """The weights of the multi-GPU plan (zpaqhip_block_costs: plaintext bytes x cycles per byte of the block's
     kernel) against the clock: 1 800 blocks of the l1 / mid / max models in three sizes (more blocks per kernel family and
     shard than the GPU has CUs, so a shard's kernel time is its work, not its longest block), dealt to two ranks
     longest-first; each rank's shard is decoded by zpaqhip_decode_blocks_device(ids = shard) — one after the other on

@@ -88,9 +88,9 @@ def test_block_costs_weigh_plaintext_size_and_model_depth():
     c = [int(x) for x in z.block_costs(s, sc)]
     assert c[0] < c[1] < c[2]                                # same plaintext: deeper model, higher cost
     assert c[1] == 3 * c[3]                                  # same model: cost follows the plaintext size
-    assert c[0] == 30000 * 170 and c[1] == 30000 * 1600 and c[2] == 30000 * 3100
+    assert c[0] == 30000 * 1100 and c[1] == 30000 * 9200 and c[2] == 30000 * 17300
     coded = int(sc.segments[sc.blocks[4].first_seg].data_len)
-    assert c[4] == 4 * coded * 1600                          # no size in the comment: 4 x coded bytes
+    assert c[4] == 4 * coded * 9200                          # no size in the comment: 4 x coded bytes
     plan = multigpu.lpt_assign(c, 2)
     loads = [sum(c[i] for i in sh) for sh in plan]
     assert max(loads) <= 0.6 * sum(c)                        # (by coded bytes alone the max block would be paired with mid)
@@ -129,7 +129,7 @@ job = multigpu.ShardedJob.from_parts(None, part, dist, None)
 assert job.stream_len == stream.size and np.array_equal(job.h_stream, stream)
 assert job.sc.n_blocks == 7 and [int(b.tag_off) for b in job.sc.blocks] == [int(b.tag_off) for b in sc.blocks]
 costs = [int(x) for x in z.block_costs(stream, sc)]
-assert costs == [3000 * 170] * 7
+assert costs == [3000 * 1100] * 7
 assert job.plan == multigpu.lpt_assign(costs, 2) and job.shard == job.plan[rank]
 def fake(ids):        # CPU stand-in for the HIP decode of a shard
     return [[0, len(oracle.decompress(stream[int(offs[b]):int(offs[b + 1])].tobytes()))] for b in ids]

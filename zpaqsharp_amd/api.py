@@ -84,7 +84,7 @@ def scan(stream, partial: bool = False):
 
 
 def block_costs(stream, sc: "ScanResult") -> np.ndarray:
-    """zpaqhip_block_costs: estimated decode cost per block (plaintext bytes x instructions per byte of the block's
+    """zpaqhip_block_costs: estimated decode cost per block (plaintext bytes x cycles per byte of the block's
     kernel), the weight of every multi-GPU plan (multigpu.py, zpaqhip_decompress_multi).  Host-side."""
     L = _lib.load()
     a = _as_u8(stream)

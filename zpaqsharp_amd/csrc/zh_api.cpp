@@ -1101,9 +1101,8 @@ int zpaqhip_decompress(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint8_t
 }
 
 // Estimated decode cost of every block: plaintext bytes (the decimal size in the comments when it is plausible, else
-// 4 x the coded bytes) x the decoder wavefront's instructions per plaintext byte of the kernel the block's header selects
-// (static ISA counts, tools/count_instr.py; a block's decode time is its bit count x the depth of its model, not its
-// coded size).  Host-side only.
+// 4 x the coded bytes) x the cycles per plaintext byte of the kernel the block's header selects (measured, profiles/r03;
+// a block's decode time is its bit count x the depth of its model, not its coded size).  Host-side only.
 int zpaqhip_block_costs(const uint8_t *in, size_t in_len, const zpaqhip_block *blocks, size_t n_blocks,
                         const zpaqhip_segment *segs, size_t n_segs, uint64_t *cost, zpaqhip_err *err) {
   if ((!in && in_len) || (!blocks && n_blocks) || (!segs && n_segs) || (!cost && n_blocks)) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
@@ -1120,16 +1119,18 @@ int zpaqhip_block_costs(const uint8_t *in, size_t in_len, const zpaqhip_block *b
       ZhModel m;
       std::vector<uint8_t> code;
       zpaqhip_err e2{};
-      uint64_t w = 1000;                                  // a header the model builder refuses costs nothing real; keep it finite
+      uint64_t w = 6000;                                  // a header the model builder refuses costs nothing real; keep it finite
       if (build_model(in + B.hdr_off, B.hdr_len, m, code, &e2) == ZPAQHIP_OK) {
         const uint32_t fam = m.kind & 255u;
         const bool pcomp = (m.ph | m.pm) != 0;
-        w = fam == ZH_FAM_STORE ? (pcomp ? 40u : 4u)                  // zh_store.hip: wave-wide copy / LZ77 / inverse BWT
-            : fam == ZH_FAM_CM1 ? 170u                               // zh_cm_fast.h
-            : fam == ZH_FAM_CHAIN + 1 ? 1000u : fam == ZH_FAM_CHAIN + 2 ? 1600u : fam == ZH_FAM_CHAIN + 3 ? 3100u   // zh_chain2.hip min / mid / max
-            : fam == ZH_FAM_CHAIN ? 600u + 350u * m.n                 // zh_chain.hip: level walk at run time
-            : 1500u + 2500u * m.n;                                    // zh_generic.hip: one lane, tables in HBM
-        if (pcomp && fam != ZH_FAM_STORE) w += 300;
+        // measured cycles of the owning workgroup per plaintext byte (profiles/r03: 256 x 4 MiB, one block per CU), rounded;
+        // estimates for the fallback kernels
+        w = fam == ZH_FAM_STORE ? (pcomp ? 120u : 30u)                // zh_store.hip: wave-wide copy / LZ77 / inverse BWT
+            : fam == ZH_FAM_CM1 ? 1100u                              // zh_cm.hip
+            : fam == ZH_FAM_CHAIN + 1 ? 6200u : fam == ZH_FAM_CHAIN + 2 ? 9200u : fam == ZH_FAM_CHAIN + 3 ? 17300u   // zh_chain2.hip min / mid / max
+            : fam == ZH_FAM_CHAIN ? 4000u + 2200u * m.n               // zh_chain.hip: level walk at run time
+            : 10000u + 16000u * m.n;                                  // zh_generic.hip: one lane, tables in HBM
+        if (pcomp && fam != ZH_FAM_STORE) w += 1500;
       }
       it = per_byte.emplace(key, w).first;
     }

@@ -11,7 +11,7 @@ KiB-scale traffic:
     all_gather(per-block {status, out_len})  ->  every rank holds the result table
 
 Who decodes what is either STATIC — longest-processing-time-first over the estimated block
-costs (zpaqhip_block_costs: plaintext bytes x instructions per byte of the block's kernel) — or
+costs (zpaqhip_block_costs: plaintext bytes x cycles per byte of the block's kernel) — or
 DYNAMIC: the cost-ordered blocks are dealt into chunks of `queue_blocks` (256: one block per CU of
 the GPU that takes the chunk), chunk k = every K-th block of that order, and every rank pulls the
 next chunk from one shared counter whenever it has finished one (`WorkQueue`; the counter is an
