@@ -201,7 +201,8 @@ int zpaqhip_decompress_cb(zpaqhip_ctx *ctx, zpaqhip_read_fn read_fn, zpaqhip_wri
  * (LibZPAQ.compressBlock writes it, LibZPAQ.cs:298-300) every device copies its blocks straight to their final place;
  * a block without a plausible size, or with a wrong one, is kept in a host buffer and put in place (it and what
  * follows it) when all sizes are known — no block is decoded twice.  A damaged block ends the call with its error
- * after every block before it has been delivered (*out_len = their bytes).  No context is needed or kept.
+ * after every block before it has been delivered (*out_len = their bytes).  No context is needed; the ones the call
+ * makes are kept for the next call (zpaqhip_multi_trim).
  * The _stats form also fills per_device[0..n_devices) (kernel_ms, blocks, ... summed over the chunks a device took;
  * launches = chunks). */
 int zpaqhip_decompress_multi(const int *devices, size_t n_devices, const uint8_t *in, size_t in_len,
@@ -210,6 +211,10 @@ int zpaqhip_decompress_multi(const int *devices, size_t n_devices, const uint8_t
 int zpaqhip_decompress_multi_stats(const int *devices, size_t n_devices, const uint8_t *in, size_t in_len,
                                    uint8_t *out, size_t out_cap, size_t *out_len,
                                    const zpaqhip_opts *opts, zpaqhip_stats *per_device, zpaqhip_err *err);
+
+/* zpaqhip_decompress_multi keeps the contexts it has used (one per device thread: tables, arena, streams) for its next
+ * call; this destroys the idle ones and gives their device memory back. */
+void zpaqhip_multi_trim(void);
 
 /* Estimated decode cost of each block of a scanned stream, the weight every multi-GPU plan here uses: plaintext bytes
  * (the comment's decimal size when plausible, else 4 x coded bytes) x the cycles per plaintext byte of the kernel

@@ -488,6 +488,8 @@ def test_multi_device_entry_point_with_contexts_sharing_this_gpu(ctx):
         assert got.tobytes() == b"".join(parts[:5])
     with pytest.raises(z.ZpaqError):
         z.decompress_multi([0, 0], bytes(bad))
+    z.multi_trim()                                               # the contexts the calls above kept are destroyed; the next call makes new ones
+    assert z.decompress_multi([0, 0], s2, verify_sha1=True, queue_blocks=2).tobytes() == b"".join(parts)
 
 
 def test_multi_device_queue_on_an_archive_that_mixes_models(ctx):

@@ -59,7 +59,7 @@ WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_int)
 SYMBOLS = ("zpaqhip_version", "zpaqhip_strerror", "zpaqhip_device_count", "zpaqhip_ctx_create",
            "zpaqhip_ctx_destroy", "zpaqhip_last_stats", "zpaqhip_scan", "zpaqhip_decompress",
            "zpaqhip_decompress_segments", "zpaqhip_decompress_cb", "zpaqhip_decode_blocks_device", "zpaqhip_read_device_tables",
-           "zpaqhip_block_pcomp", "zpaqhip_decompress_multi", "zpaqhip_decompress_multi_stats", "zpaqhip_block_costs")
+           "zpaqhip_block_pcomp", "zpaqhip_decompress_multi", "zpaqhip_decompress_multi_stats", "zpaqhip_block_costs", "zpaqhip_multi_trim")
 
 _lib = None
 
@@ -103,5 +103,6 @@ def load():
     L.zpaqhip_decompress_multi_stats.argtypes = [C.POINTER(C.c_int), sz, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(Opts),
                                                  C.POINTER(Stats), errp]
     L.zpaqhip_block_costs.argtypes = [vp, sz, C.POINTER(Block), sz, C.POINTER(Segment), sz, vp, errp]
+    L.zpaqhip_multi_trim.restype = None
     _lib = L
     return L

@@ -131,6 +131,11 @@ def decompress_multi(devices: Sequence[int], stream, out_cap: Optional[int] = No
     return out[:n.value]
 
 
+def multi_trim() -> None:
+    """zpaqhip_multi_trim: destroy the contexts decompress_multi keeps between calls."""
+    _lib.load().zpaqhip_multi_trim()
+
+
 def make_opts(verify_sha1: bool = False, max_concurrent: int = 0, kernel: int = 0, zpaql_budget: int = 0,
               batch_blocks: int = 0, queue_blocks: int = 0) -> Opts:
     o = Opts()

@@ -13,6 +13,7 @@
 #include <atomic>
 #include <chrono>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -1142,6 +1143,34 @@ int zpaqhip_block_costs(const uint8_t *in, size_t in_len, const zpaqhip_block *b
   return ZPAQHIP_OK;
 }
 
+// Contexts zpaqhip_decompress_multi has used stay alive between calls (the arena of a context is tens of GB for the larger
+// models: allocating and faulting it in on every call cost more than the decode of a small archive): a device thread takes
+// one of its device's from this pool, or makes one, and puts it back.  zpaqhip_multi_trim() destroys the idle ones.
+namespace {
+std::mutex g_pool_mu;
+std::map<int, std::vector<zpaqhip_ctx *>> g_pool;
+zpaqhip_ctx *pool_take(int device, int *rc, zpaqhip_err *err) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto &v = g_pool[device];
+    if (!v.empty()) { zpaqhip_ctx *c = v.back(); v.pop_back(); *rc = ZPAQHIP_OK; return c; }
+  }
+  zpaqhip_ctx *c = nullptr;
+  *rc = zpaqhip_ctx_create(device, &c, err);
+  return *rc ? nullptr : c;
+}
+void pool_give(zpaqhip_ctx *c) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pool[c->device].push_back(c);
+}
+}  // namespace
+
+extern "C" void zpaqhip_multi_trim(void) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (auto &kv : g_pool) for (zpaqhip_ctx *c : kv.second) zpaqhip_ctx_destroy(c);
+  g_pool.clear();
+}
+
 // Several GPUs of one node: one context and one host thread per entry of `devices`, all pulling from ONE work queue.
 //   queue   the blocks sorted by estimated cost (zpaqhip_block_costs) are dealt into K = ceil(n / queue_blocks) chunks,
 //           chunk k = every K-th block of that order starting at k (each chunk is a cross-section of the cost
@@ -1189,9 +1218,9 @@ int zpaqhip_decompress_multi_stats(const int *devices, size_t n_dev, const uint8
   std::vector<Job> jobs(n_dev);
   auto worker = [&](size_t r) {
     Job &J = jobs[r];
-    zpaqhip_ctx *c = nullptr;
-    J.rc = zpaqhip_ctx_create(devices[r], &c, &J.err);
-    if (J.rc) { abort_all = true; return; }
+    zpaqhip_ctx *c = pool_take(devices[r], &J.rc, &J.err);
+    if (!c) { abort_all = true; return; }
+    c->mem_share = 1;
     for (size_t k = 0; k < n_dev; ++k) c->mem_share += k != r && devices[k] == devices[r];
     std::vector<uint8_t> sub;
     std::vector<size_t> ids;
@@ -1204,13 +1233,18 @@ int zpaqhip_decompress_multi_stats(const int *devices, size_t n_dev, const uint8
       for (size_t i = k; i < nb; i += K) ids.push_back(order[i]);
       std::sort(ids.begin(), ids.end());                 // stream order inside the chunk: the pipeline delivers in order
       sub.clear(); place.clear(); cap.clear();
+      // a chunk of consecutive blocks (one chunk for the whole archive, typically) is decoded where it lies; a strided one
+      // is gathered first
+      const bool run = ids.back() - ids.front() + 1 == ids.size();
       for (size_t b : ids) {
-        sub.insert(sub.end(), in + so.blocks[b].tag_off, in + so.blocks[b].end_off);
+        if (!run) sub.insert(sub.end(), in + so.blocks[b].tag_off, in + so.blocks[b].end_off);
         place.push_back(slot_off[b]); cap.push_back(slot_cap[b]);
       }
       sizes.assign(ids.size(), 0);
       sp.assign(ids.size(), std::vector<uint8_t>());
-      Source src; src.mem = sub.data(); src.mem_len = sub.size();
+      Source src;
+      if (run) { src.mem = in + so.blocks[ids.front()].tag_off; src.mem_len = (size_t)(so.blocks[ids.back()].end_off - so.blocks[ids.front()].tag_off); }
+      else { src.mem = sub.data(); src.mem_len = sub.size(); }
       Sinkk sink;
       sink.mem = out; sink.cap = out_cap; sink.place = place.data(); sink.place_cap = cap.data(); sink.sizes = &sizes; sink.spill = &sp;
       zpaqhip_err e2{};
@@ -1230,7 +1264,8 @@ int zpaqhip_decompress_multi_stats(const int *devices, size_t n_dev, const uint8
       }
       for (size_t j = 0; j < good; ++j) { real[ids[j]] = sizes[j]; spill[ids[j]].swap(sp[j]); done[ids[j]] = 1; }
     }
-    zpaqhip_ctx_destroy(c);
+    if (J.rc && J.bad < 0) zpaqhip_ctx_destroy(c);       // a failure of the call itself (HIP, memory): do not keep that context
+    else pool_give(c);
   };
   {
     std::vector<std::thread> th;
