@@ -32,12 +32,22 @@ def main():
     runs = (("one context, batch pipeline", lambda: ctx.decompress(s, out_cap=bs * a.blocks)),
             ("multi [0], queue_blocks 256", lambda: z.decompress_multi([0], s, out_cap=bs * a.blocks)),
             ("multi [0, 0], queue_blocks 64", lambda: z.decompress_multi([0, 0], s, out_cap=bs * a.blocks, queue_blocks=64)))
+    def via_callbacks():                                      # zpaqhip_decompress_cb: Reader / Writer shaped callbacks
+        mv, pos, chunks = memoryview(s), [0], []
+
+        def rd(n):
+            b = mv[pos[0]:pos[0] + n]
+            pos[0] += len(b)
+            return bytes(b)
+        ctx.decompress_cb(rd, chunks.append)
+        return np.frombuffer(b"".join(chunks), np.uint8)
+    runs = runs + (("one context, Reader / Writer callbacks", via_callbacks),)
     for name, fn in runs:
         fn()                                                  # warm-up
         t0 = time.time()
         out = fn()
         dt = time.time() - t0
-        print(f"{a.model} {a.blocks} x {a.kib} KiB  {name:32s} {bs * a.blocks / dt / 1e6:8.1f} MB/s host to host  exact={check(out)}", flush=True)
+        print(f"{a.model} {a.blocks} x {a.kib} KiB  {name:40s} {bs * a.blocks / dt / 1e6:8.1f} MB/s host to host  exact={check(out)}", flush=True)
 
 
 if __name__ == "__main__":
