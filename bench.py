@@ -51,12 +51,26 @@ HBM_COPY_GBPS = 6290.0          # same guide: measured copy peak (SURVEY.md §8d
 CLOCK_GHZ = 2.4                 # max shader clock (same guide)
 
 
-def source_hash():
-    """Identifies the kernels a PMC summary or an instruction count was taken with: SHA-1 over the device sources of
-    libzpaqhip (zpaqsharp_amd/csrc/*.hip and the headers they include; host-only *.cpp files do not change a kernel)."""
+# The device sources each hot kernel is compiled from (the .hip file and every header it includes): a PMC summary or an
+# instruction count belongs to a kernel, and stays valid while THAT kernel's sources do
+KERNEL_SOURCES = {
+    "l1": ("zh_cm.hip", "zh_cm_fast.h", "zh_core.h", "zh_dev.h", "zh_model.h"),
+    "chain2": ("zh_chain2.hip", "zh_c2_common.h", "zh_zpaql_native.h", "zh_core.h", "zh_dev.h", "zh_model.h"),
+}
+
+
+def source_hash(model=None):
+    """Identifies the kernel a PMC summary or an instruction count was taken with: SHA-1 over the device sources of the
+    decode kernel of `model` (l1 -> zh_cm.hip and its headers; min / mid / max[+e8e9] -> zh_chain2.hip and its headers);
+    model None: every device source of libzpaqhip (zpaqsharp_amd/csrc/*.hip, *.h)."""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "zpaqsharp_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
+    if model is None:
+        files = sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip")))
+    else:
+        base = model.replace("_", "+").split("+")[0]
+        files = [os.path.join(d, f) for f in sorted(KERNEL_SOURCES["l1" if base == "l1" else "chain2"])]
+    for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -70,7 +84,7 @@ def pmc_traffic(model, nb, bs):
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"pmc_{tag}.json")))
     if not cands:
         return None, "no PMC summary committed for this workload"
-    cur = source_hash()
+    cur = source_hash(model)
     for f in reversed(cands):
         try:
             d = json.load(open(f))
@@ -158,7 +172,7 @@ def decoder_instr_per_byte(base_model):
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"instr_{sym}.json"))) if sym else []
     if not cands:
         return None, "no instruction count committed for this kernel (tools/count_instr.py)"
-    cur = source_hash()
+    cur = source_hash(base_model)
     for f in reversed(cands):
         try:
             d = json.load(open(f))

@@ -169,5 +169,5 @@ def test_committed_instruction_counts_belong_to_these_kernel_sources(tmp_path):
         n, src = bench.decoder_instr_per_byte(model)
         assert n is not None, (sym, src)
         fresh = json.load(open(os.path.join(str(tmp_path), f"instr_{sym}.json")))
-        assert fresh["instr_per_byte_static"] == n and fresh["src_hash"] == bench.source_hash()
+        assert fresh["instr_per_byte_static"] == n and fresh["src_hash"] == bench.source_hash(model)
         assert 100 <= n <= 4000

@@ -95,7 +95,6 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03"))
     a = ap.parse_args()
     import bench
-    src = bench.source_hash()
     funcs = disassemble(a.lib)
     os.makedirs(a.out, exist_ok=True)
     for tag, (sym, nsteps) in KERNELS.items():
@@ -117,7 +116,7 @@ def main():
                  "salu" if mn.startswith("s_") else "lds" if mn.startswith("ds_") else
                  "vmem" if mn.startswith(("buffer_", "global_", "flat_", "scratch_")) else "valu")
             kinds[k] += 1
-        rec = {"kernel": sym, "model": tag, "src_hash": src, "instr_per_byte_static": len(body),
+        rec = {"kernel": sym, "model": tag, "src_hash": bench.source_hash(tag), "instr_per_byte_static": len(body),
                "instr_between_decoder_steps": per_step, "loop_bytes": ins[hi][0] - ins[lo][0], "mix": kinds,
                "how": f"tools/count_instr.py: innermost loop around the {nsteps} s_mul_hi_u32 decoder steps of a byte, layout order, s_nop excluded"}
         with open(os.path.join(a.out, f"instr_{sym}.json"), "w") as f:

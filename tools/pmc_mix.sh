@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=$(echo $MODEL | tr '+' '_')
 OUT=gpurun_out/instmix_$TAG; mkdir -p $OUT
 TXT=$OUT/instmix_${TAG}_256x$((BS >> 10))KiB.txt
-python3 -c "import bench; print('src_hash', bench.source_hash())" > $TXT
+python3 -c "import bench; print('src_hash', bench.source_hash('$MODEL'))" > $TXT
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
   T=$(echo $C | tr ' ' '_')
   rocprofv3 --pmc $C --output-format csv -d $OUT/$T -- python3 bench.py --model $MODEL --blocks 256 --block-bytes $BS --steps 1 --warmup 0 --no-extras --no-cpu-baseline --no-verify --cache-dir /tmp/zc > $OUT/$T.json 2> $OUT/$T.err || { tail -3 $OUT/$T.err; }

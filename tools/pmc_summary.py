@@ -15,7 +15,7 @@ import bench  # noqa: E402
 
 def main():
     out, model, nb, bs = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-    res = {"src_hash": bench.source_hash(), "model": model, "blocks": nb, "block_bytes": bs}
+    res = {"src_hash": bench.source_hash(model), "model": model, "blocks": nb, "block_bytes": bs}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         vals, name = [], None
         for f in glob.glob(os.path.join(out, f"pmc_{c}", "*", "*counter_collection.csv")):
