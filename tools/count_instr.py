@@ -28,7 +28,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 # kernel symbol, decoder steps with a multiply inside the byte loop (zh_cm_fast.h decodes the EOS flag, p = 0, with a compare)
-KERNELS = {"l1": ("zh_decode_cm", 8), "min": ("zh_decode_c2_min", 9), "mid": ("zh_decode_c2_mid", 9), "max": ("zh_decode_c2_max", 9)}
+# ... and the bytes one pass of the loop decodes (zh_cm_fast.h lays its body out twice)
+KERNELS = {"l1": ("zh_decode_cm", 16, 2), "min": ("zh_decode_c2_min", 9, 1), "mid": ("zh_decode_c2_mid", 9, 1), "max": ("zh_decode_c2_max", 9, 1)}
 
 
 def disassemble(lib):
@@ -97,7 +98,7 @@ def main():
     import bench
     funcs = disassemble(a.lib)
     os.makedirs(a.out, exist_ok=True)
-    for tag, (sym, nsteps) in KERNELS.items():
+    for tag, (sym, nsteps, nbytes) in KERNELS.items():
         ins = funcs.get(sym)
         if not ins:
             print(f"{sym}: not in the library")
@@ -116,12 +117,12 @@ def main():
                  "salu" if mn.startswith("s_") else "lds" if mn.startswith("ds_") else
                  "vmem" if mn.startswith(("buffer_", "global_", "flat_", "scratch_")) else "valu")
             kinds[k] += 1
-        rec = {"kernel": sym, "model": tag, "src_hash": bench.source_hash(tag), "instr_per_byte_static": len(body),
+        rec = {"kernel": sym, "model": tag, "src_hash": bench.source_hash(tag), "instr_per_byte_static": len(body) // nbytes, "bytes_per_loop_pass": nbytes,
                "instr_between_decoder_steps": per_step, "loop_bytes": ins[hi][0] - ins[lo][0], "mix": kinds,
                "how": f"tools/count_instr.py: innermost loop around the {nsteps} s_mul_hi_u32 decoder steps of a byte, layout order, s_nop excluded"}
         with open(os.path.join(a.out, f"instr_{sym}.json"), "w") as f:
             json.dump(rec, f, indent=1)
-        print(f"{sym}: {len(body)} instructions per byte (static), between decoder steps {per_step}, {kinds}")
+        print(f"{sym}: {len(body) // nbytes} instructions per byte (static), between decoder steps {per_step}, {kinds}")
 
 
 if __name__ == "__main__":

@@ -77,10 +77,10 @@
   ZH_FAST_CHK                                                         \
   "s_branch .Lzh_bk" #N "_%=\n\t"
 // ... after the byte's last bit
-#define ZH_FAST_RENORM_LAST(N)                                        \
+#define ZH_FAST_RENORM_LAST(N, S)                                     \
   ".Lzh_rn" #N "_%=:\n\t"                                             \
   ZH_FAST_SHIFT_IN(N)                                                 \
-  ZH_FAST_CHK8                                                        \
+  ZH_FAST_CHK8(S)                                                     \
   "s_branch .Lzh_bk" #N "_%=\n\t"
 
 #define ZH_FAST_CHK                                                   \
@@ -91,11 +91,11 @@
 
 // The last bit's renormalisation: a state out of range is not an error of THIS byte (Decoder.cs:138 raises it at the
 // next decode() call), so the byte is still published and the loop is left; the C++ body's EOS test reports it.
-#define ZH_FAST_CHK8                                                  \
+#define ZH_FAST_CHK8(S)                                               \
   "s_cmp_lt_u32 %[curr], %[low]\n\t"                                  \
-  "s_cbranch_scc1 .Lzh_oor_%=\n\t"                                    \
+  "s_cbranch_scc1 .Lzh_oor" #S "_%=\n\t"                              \
   "s_cmp_gt_u32 %[curr], %[high]\n\t"                                 \
-  "s_cbranch_scc1 .Lzh_oor_%=\n\t"
+  "s_cbranch_scc1 .Lzh_oor" #S "_%=\n\t"
 
 // byte = (j << 4) + j2 - 272;  message to wave B: tag(t) << 25 | byte << 15 | slot, written by lane 0 to the ring slot
 // of message t (the other lanes of `vr` hold the addresses of their own dummy words: no exec switch around the write);
@@ -125,11 +125,11 @@
 // Invariant on entry and at every .Lzh_byte: low <= curr <= high unless the coder is unprimed (curr == 0 < low) — every
 // renormalisation inside the loop re-checks it (ZH_FAST_CHK / ZH_FAST_CHK8), a split keeps it — so the EOS flag (p = 0:
 // y = curr <= low) needs one compare.  zh_cm.hip enters the loop only with the state in range.
-#define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_) \
-  asm volatile(                                                       \
-  "v_mov_b32_e32 v249, 0\n\t"                                         \
-  ".p2align 8\n"                                                      \
-  ".Lzh_byte_%=:\n\t"                                                 \
+// One byte of the loop (hot part) and its out-of-line parts; S = copy suffix, E = label number of the renormalisation after
+// the EOS flag, N1..N8 = label numbers of the eight bit steps.  The loop body is laid out TWICE (a taken s_branch costs a lone
+// wave ~21 cycles, tools/ubench/salu_bench: the second copy falls through from the first and only it branches back; same-box
+// A/B: one copy 564.6, two 571.6, four 568.7 MB/s).
+#define ZH_CM_FAST_BYTE(S, E, N1, N2, N3, N4, N5, N6, N7, N8)         \
   /* window lookup: lane s of `tag` holds the window id cached in slot s */ \
   "s_bfe_u32 s81, %[h0], %[bfe]\n\t"                                  \
   "v_cmp_eq_u32_e32 vcc, s81, %[tag]\n\t"                             \
@@ -141,8 +141,8 @@
   "s_min_u32 s83, s83, 13\n\t"                                        \
   "s_sub_u32 s89, %[t], %[bdone]\n\t"                                 \
   "s_cmp_gt_u32 s89, s83\n\t"                                         \
-  "s_cbranch_scc1 .Lzh_fresh_%=\n"                                    \
-  ".Lzh_ok_%=:\n\t"                                                   \
+  "s_cbranch_scc1 .Lzh_fresh" #S "_%=\n"                              \
+  ".Lzh_ok" #S "_%=:\n\t"                                             \
   /* cached probabilities: lane j <- node j of the first nibble; lane (q, j) <- node j of groups q, q+4, q+8, q+12. */ \
   /* Issued before the remaining tests so that their latency is covered; a slow exit waits for them. */ \
   "v_lshl_add_u32 v252, s82, 5, %[la]\n\t"                            \
@@ -158,13 +158,13 @@
   "s_add_u32 %[low], %[low], 1\n\t"                                   \
   "s_xor_b32 s84, %[high], %[low]\n\t"                                \
   "s_cmp_lt_u32 s84, 0x1000000\n\t"                                   \
-  "s_cbranch_scc1 .Lzh_rn0_%=\n"                                      \
-  ".Lzh_bk0_%=:\n\t"                                                  \
+  "s_cbranch_scc1 .Lzh_rn" #E "_%=\n"                                 \
+  ".Lzh_bk" #E "_%=:\n\t"                                             \
   "s_waitcnt lgkmcnt(0)\n\t"                                          \
-  ZH_FAST_STEP1("v249", "s90", "1", 1)                               \
-  ZH_FAST_STEP("v249", "s90", "s90", 2)                               \
-  ZH_FAST_STEP("v249", "s90", "s90", 3)                               \
-  ZH_FAST_STEP("v249", "s90", "s90", 4)                               \
+  ZH_FAST_STEP1("v249", "s90", "1", N1)                               \
+  ZH_FAST_STEP("v249", "s90", "s90", N2)                              \
+  ZH_FAST_STEP("v249", "s90", "s90", N3)                              \
+  ZH_FAST_STEP("v249", "s90", "s90", N4)                              \
   /* second nibble: group n1 = quad (n1 & 3), element n1 >> 2 */      \
   "s_lshl_b32 s80, s90, 2\n\t"                                        \
   "s_and_b32 s80, s80, 48\n\t"                                        \
@@ -173,42 +173,53 @@
   "v_lshrrev_b64 v[250:251], s80, v[250:251]\n\t"                     \
   "v_lshlrev_b32_e32 v250, 16, v250\n\t"                              \
   "s_add_u32 s80, s89, 1\n\t"                                         \
-  ZH_FAST_STEP1("v250", "s91", "s80", 5)                               \
+  ZH_FAST_STEP1("v250", "s91", "s80", N5)                             \
   "s_add_u32 s80, s89, s91\n\t"                                       \
-  ZH_FAST_STEP("v250", "s91", "s80", 6)                               \
+  ZH_FAST_STEP("v250", "s91", "s80", N6)                              \
   "s_add_u32 s80, s89, s91\n\t"                                       \
-  ZH_FAST_STEP("v250", "s91", "s80", 7)                               \
+  ZH_FAST_STEP("v250", "s91", "s80", N7)                              \
   "s_add_u32 s80, s89, s91\n\t"                                       \
-  ZH_FAST_STEP("v250", "s91", "s80", 8)                               \
-  ZH_FAST_EPILOGUE                                                    \
-  "s_branch .Lzh_byte_%=\n"                                           \
-  /* ---- out of line ---- */                                         \
+  ZH_FAST_STEP("v250", "s91", "s80", N8)                              \
+  ZH_FAST_EPILOGUE
+#define ZH_CM_FAST_COLD(S, E, N1, N2, N3, N4, N5, N6, N7, N8)         \
   /* wave B is behind: re-read its progress counter a bounded number of times, then give up */ \
-  ".Lzh_fresh_%=:\n\t"                                                \
+  ".Lzh_fresh" #S "_%=:\n\t"                                          \
   "s_mov_b32 s80, 48\n"                                               \
-  ".Lzh_spin_%=:\n\t"                                                 \
+  ".Lzh_spin" #S "_%=:\n\t"                                           \
   "ds_read_b32 v252, %[bsa]\n\t"                                      \
   "s_waitcnt lgkmcnt(0)\n\t"                                          \
   "v_readfirstlane_b32 %[bdone], v252\n\t"                            \
   "s_sub_u32 s89, %[t], %[bdone]\n\t"                                 \
   "s_cmp_gt_u32 s89, s83\n\t"                                         \
-  "s_cbranch_scc0 .Lzh_ok_%=\n\t"                                     \
+  "s_cbranch_scc0 .Lzh_ok" #S "_%=\n\t"                               \
   "s_sub_u32 s80, s80, 1\n\t"                                         \
   "s_cmp_lg_u32 s80, 0\n\t"                                           \
-  "s_cbranch_scc1 .Lzh_spin_%=\n\t"                                   \
+  "s_cbranch_scc1 .Lzh_spin" #S "_%=\n\t"                             \
   "s_branch .Lzh_slow_%=\n\t"                                         \
-  ZH_FAST_RENORM(0)                                                   \
-  ZH_FAST_RENORM(1)                                                   \
-  ZH_FAST_RENORM(2)                                                   \
-  ZH_FAST_RENORM(3)                                                   \
-  ZH_FAST_RENORM(4)                                                   \
-  ZH_FAST_RENORM(5)                                                   \
-  ZH_FAST_RENORM(6)                                                   \
-  ZH_FAST_RENORM(7)                                                   \
-  ZH_FAST_RENORM_LAST(8)                                              \
-  ".Lzh_oor_%=:\n\t"                                                  \
+  ZH_FAST_RENORM(E)                                                   \
+  ZH_FAST_RENORM(N1)                                                  \
+  ZH_FAST_RENORM(N2)                                                  \
+  ZH_FAST_RENORM(N3)                                                  \
+  ZH_FAST_RENORM(N4)                                                  \
+  ZH_FAST_RENORM(N5)                                                  \
+  ZH_FAST_RENORM(N6)                                                  \
+  ZH_FAST_RENORM(N7)                                                  \
+  ZH_FAST_RENORM_LAST(N8, S)                                          \
+  ".Lzh_oor" #S "_%=:\n\t"                                            \
   ZH_FAST_EPILOGUE                                                    \
-  "s_branch .Lzh_slow_%=\n"                                           \
+  "s_branch .Lzh_slow_%=\n"
+
+#define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_) \
+  asm volatile(                                                       \
+  "v_mov_b32_e32 v249, 0\n\t"                                         \
+  ".p2align 8\n"                                                      \
+  ".Lzh_byte_%=:\n\t"                                                 \
+  ZH_CM_FAST_BYTE(a, 0, 1, 2, 3, 4, 5, 6, 7, 8)                       \
+  ZH_CM_FAST_BYTE(b, 10, 11, 12, 13, 14, 15, 16, 17, 18)              \
+  "s_branch .Lzh_byte_%=\n"                                           \
+  /* ---- out of line ---- */                                         \
+  ZH_CM_FAST_COLD(a, 0, 1, 2, 3, 4, 5, 6, 7, 8)                       \
+  ZH_CM_FAST_COLD(b, 10, 11, 12, 13, 14, 15, 16, 17, 18)              \
   ".Lzh_corrupt_%=:\n\t"                                              \
   "s_mov_b32 %[code], 1\n\t"                                          \
   "s_branch .Lzh_end_%=\n"                                            \
