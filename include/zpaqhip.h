@@ -118,8 +118,8 @@ typedef struct zpaqhip_opts {
   uint32_t kernel;            /* 0 auto; 1 force the generic (one-lane) kernel; 3 prefer the lane-per-component kernel;
                                  4 lane-per-component without model specialisation; 5 the run-time-level form of the
                                  lane-per-component kernel also for the built-in min/mid/max models (cross-check);
-                                 8 the three-wave form (decoder wave, speculating model wave, helper wave) for the built-in
-                                 mid/max models, 7 the same without speculation (experimental: bit-exact, not faster yet) */
+                                 7 / 8: ignored (= auto) by the product build; a library built with `make EXPERIMENTS=1` runs the
+                                 measured-and-not-kept three-wave form of mid/max there (tools/experiments/zh_chain3.hip) */
   uint64_t zpaql_budget;      /* runaway-program guard, per run() call: max ZPAQL instructions on the interpreter, max backward
                                  jumps in an ahead-of-time translated program (a translation checks where it can loop);
                                  0 = default (1<<32).  Exceeding it ends the block with ZPAQHIP_E_BUDGET */
@@ -201,8 +201,12 @@ int zpaqhip_decompress_cb(zpaqhip_ctx *ctx, zpaqhip_read_fn read_fn, zpaqhip_wri
  * (LibZPAQ.compressBlock writes it, LibZPAQ.cs:298-300) every device copies its blocks straight to their final place;
  * a block without a plausible size, or with a wrong one, is kept in a host buffer and put in place (it and what
  * follows it) when all sizes are known — no block is decoded twice.  A damaged block ends the call with its error
- * after every block before it has been delivered (*out_len = their bytes).  No context is needed; the ones the call
- * makes are kept for the next call (zpaqhip_multi_trim).
+ * after every block before it has been delivered (*out_len = their bytes).  (Difference to zpaqhip_decompress /
+ * zpaqhip_decompress_cb, which write as they decode like the reference: those also deliver the bytes the damaged block
+ * itself produced before its error; this entry point places whole blocks only, so its plaintext is a prefix of theirs.
+ * Pinned by test_multi_device_entry_point_with_contexts_sharing_this_gpu.)  No context is needed; the ones the call
+ * makes are kept for the next call (zpaqhip_multi_trim); idle ones beyond what a call uses on a device, and all idle
+ * ones of a device whose memory a later launch needs, are released by the library itself.
  * The _stats form also fills per_device[0..n_devices) (kernel_ms, blocks, ... summed over the chunks a device took;
  * launches = chunks). */
 int zpaqhip_decompress_multi(const int *devices, size_t n_devices, const uint8_t *in, size_t in_len,

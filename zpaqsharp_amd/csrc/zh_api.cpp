@@ -28,8 +28,11 @@ extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStrea
 extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_chain2(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof);
 extern "C" int zh_chain2_has(uint32_t spec);
+static size_t pool_trim_device(int device, size_t keep);   // idle contexts of zpaqhip_decompress_multi's pool (below)
+#ifdef ZH_WITH_CHAIN3   // make EXPERIMENTS=1: tools/experiments/zh_chain3.hip (three-wave form, measured slower; not in the product build)
 extern "C" hipError_t zh_launch_chain3(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int variant);
 extern "C" int zh_chain3_has(uint32_t spec);
+#endif
 extern "C" hipError_t zh_launch_store(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 
 
@@ -327,7 +330,23 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
   free_b += c->arena.cap;                               // our own cached arena is reusable
-  const uint64_t mem_budget = (free_b > (1ull << 30) ? free_b - (1ull << 30) : free_b / 2) / std::max(1u, c->mem_share);
+  uint64_t mem_budget = (free_b > (1ull << 30) ? free_b - (1ull << 30) : free_b / 2) / std::max(1u, c->mem_share);
+  {
+    // Idle contexts zpaqhip_decompress_multi has pooled on this device keep their arenas (tens of GB for the larger models).
+    // If this launch could not give every block (up to 256) its slot, they are released first and the budget taken again
+    // (multi([0,0,0,0]) followed by a max-model decode on a context of one's own saw a quarter of the memory).
+    uint64_t wish = 0;
+    for (uint32_t g = 0; g < ZH_NFAM; ++g) {
+      uint64_t stride = 0;
+      for (uint32_t k : groups[g]) stride = std::max<uint64_t>(stride, models[bd[k].model].arena_bytes);
+      wish += stride * std::min<uint64_t>(groups[g].size(), opts.max_concurrent ? opts.max_concurrent : 256u);
+    }
+    if (wish > mem_budget && pool_trim_device(c->device, 0)) {
+      HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      free_b += c->arena.cap;
+      mem_budget = (free_b > (1ull << 30) ? free_b - (1ull << 30) : free_b / 2) / std::max(1u, c->mem_share);
+    }
+  }
 
   HIPCHK(c->models.reserve(models.size() * sizeof(ZhModel)));
   HIPCHK(c->code.reserve(code.size() + 16));
@@ -417,8 +436,10 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     }
     else if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, slots_of[g], stream));
     else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, slots_of[g], stream));
-    else if (g > ZH_FAM_CHAIN && zh_chain3_has(g - ZH_FAM_CHAIN) && (opts.kernel == 7 || opts.kernel == 8))   // decoder ‖ model ‖ helper wave (zh_chain3.hip): opt-in
+#ifdef ZH_WITH_CHAIN3
+    else if (g > ZH_FAM_CHAIN && zh_chain3_has(g - ZH_FAM_CHAIN) && (opts.kernel == 7 || opts.kernel == 8))   // decoder ‖ model ‖ helper wave: experiment build only
       HIPCHK(zh_launch_chain3(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof ? 2 : opts.kernel == 7));
+#endif
     else if (g > ZH_FAM_CHAIN && zh_chain2_has(g - ZH_FAM_CHAIN) && opts.kernel != 5)   // per-model bit loop (zh_chain2.hip)
       HIPCHK(zh_launch_chain2(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));
     else if (g >= ZH_FAM_CHAIN) {
@@ -928,8 +949,23 @@ struct SegSink {                          // zpaqhip_decompress_segments: per-se
 
 // The pipeline.  `tolerate`: per-segment data errors do not end the call (zpaqhip_decompress_segments).
 // *stream_error: the returned code describes the stream (damage behind the delivered blocks), not a failure of the call.
+int run_pipeline_impl(zpaqhip_ctx *c, Source &src, Sinkk &sink, const zpaqhip_opts &opts, bool tolerate, SegSink *segsink,
+                      zpaqhip_err *err, bool *stream_error);
+// Every exit with an error leaves nothing in flight: copies on s_out / s_in may still be writing caller-owned (pageable) host
+// memory or reading staging the caller is about to free (the multi-device worker destroyed its spill vectors and
+// the context right after an early return).
 int run_pipeline(zpaqhip_ctx *c, Source &src, Sinkk &sink, const zpaqhip_opts &opts, bool tolerate, SegSink *segsink,
                  zpaqhip_err *err, bool *stream_error = nullptr) {
+  const int rc = run_pipeline_impl(c, src, sink, opts, tolerate, segsink, err, stream_error);
+  if (rc) {
+    if (c->s_out) (void)hipStreamSynchronize(c->s_out);
+    if (c->s_in) (void)hipStreamSynchronize(c->s_in);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+  }
+  return rc;
+}
+int run_pipeline_impl(zpaqhip_ctx *c, Source &src, Sinkk &sink, const zpaqhip_opts &opts, bool tolerate, SegSink *segsink,
+                      zpaqhip_err *err, bool *stream_error) {
   if (stream_error) *stream_error = false;
   HIPCHK(hipSetDevice(c->device));
   if (!c->s_in) {
@@ -1104,6 +1140,7 @@ int zpaqhip_decompress(zpaqhip_ctx *c, const uint8_t *in, size_t in_len, uint8_t
 // Estimated decode cost of every block: plaintext bytes (the decimal size in the comments when it is plausible, else
 // 4 x the coded bytes) x the cycles per plaintext byte of the kernel the block's header selects (measured, profiles/r03;
 // a block's decode time is its bit count x the depth of its model, not its coded size).  Host-side only.
+static constexpr uint64_t kCm1Marker = ~0ull;
 int zpaqhip_block_costs(const uint8_t *in, size_t in_len, const zpaqhip_block *blocks, size_t n_blocks,
                         const zpaqhip_segment *segs, size_t n_segs, uint64_t *cost, zpaqhip_err *err) {
   if ((!in && in_len) || (!blocks && n_blocks) || (!segs && n_segs) || (!cost && n_blocks)) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
@@ -1127,18 +1164,29 @@ int zpaqhip_block_costs(const uint8_t *in, size_t in_len, const zpaqhip_block *b
         // measured cycles of the owning workgroup per plaintext byte (profiles/r03: 256 x 4 MiB, one block per CU), rounded;
         // estimates for the fallback kernels
         w = fam == ZH_FAM_STORE ? (pcomp ? 120u : 30u)                // zh_store.hip: wave-wide copy / LZ77 / inverse BWT
-            : fam == ZH_FAM_CM1 ? 1100u                              // zh_cm.hip
+            : fam == ZH_FAM_CM1 ? kCm1Marker                         // zh_cm.hip: by coded / plain ratio, below
             : fam == ZH_FAM_CHAIN + 1 ? 6200u : fam == ZH_FAM_CHAIN + 2 ? 9200u : fam == ZH_FAM_CHAIN + 3 ? 17300u   // zh_chain2.hip min / mid / max
             : fam == ZH_FAM_CHAIN ? 4000u + 2200u * m.n               // zh_chain.hip: level walk at run time
             : 10000u + 16000u * m.n;                                  // zh_generic.hip: one lane, tables in HBM
-        if (pcomp && fam != ZH_FAM_STORE) w += 1500;
+        if (pcomp && fam != ZH_FAM_STORE) w += w == kCm1Marker ? (uint64_t)-1 : 1500u;       // (marker - 1: single CM with a post-processor)
       }
       it = per_byte.emplace(key, w).first;
     }
     uint64_t coded = 0;
     for (uint32_t i = 0; i < B.n_seg; ++i) coded += segs[B.first_seg + i].data_len;
-    const uint64_t plain = (B.usize_hint != UINT64_MAX && B.usize_hint <= (1ull << 40)) ? B.usize_hint : coded * 4;
-    cost[b] = std::max<uint64_t>(1, plain) * it->second;
+    const bool hinted = B.usize_hint != UINT64_MAX && B.usize_hint <= (1ull << 40);
+    const uint64_t plain = hinted ? B.usize_hint : coded * 4;
+    uint64_t w = it->second;
+    if (w >= kCm1Marker - 1) {
+      const uint64_t pp = w == kCm1Marker ? 0u : 1500u;
+      // zh_cm.hip: the byte loop costs the same on any data, a window miss ~3 000 cycles, and the miss rate of an order-1
+      // context follows the data's entropy — which the block shows as coded / plain.  Measured at 256 blocks per GPU
+      // (profiles/r03, r04): text 0.45 -> 1 100 cycles per byte, x86-like 0.75 -> 1 760, random 1.03 -> 3 400;
+      // piecewise linear between them (a block without a size hint counts as text)
+      const double rho = hinted && plain ? (double)coded / (double)plain : 0.45;
+      w = pp + (rho <= 0.45 ? 1100u : rho <= 0.75 ? 1100u + (uint64_t)((rho - 0.45) * 2200.0) : 1760u + (uint64_t)((std::min(rho, 1.1) - 0.75) * 5900.0));
+    }
+    cost[b] = std::max<uint64_t>(1, plain) * w;
   }
   return ZPAQHIP_OK;
 }
@@ -1164,6 +1212,18 @@ void pool_give(zpaqhip_ctx *c) {
   g_pool[c->device].push_back(c);
 }
 }  // namespace
+// Destroys the idle pooled contexts of `device` beyond the first `keep`; returns how many went.
+static size_t pool_trim_device(int device, size_t keep) {
+  std::vector<zpaqhip_ctx *> gone;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool.find(device);
+    if (it == g_pool.end()) return 0;
+    while (it->second.size() > keep) { gone.push_back(it->second.back()); it->second.pop_back(); }
+  }
+  for (zpaqhip_ctx *c : gone) zpaqhip_ctx_destroy(c);
+  return gone.size();
+}
 
 extern "C" void zpaqhip_multi_trim(void) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -1214,6 +1274,11 @@ int zpaqhip_decompress_multi_stats(const int *devices, size_t n_dev, const uint8
   }
   std::vector<std::vector<uint8_t>> spill(nb);
   std::vector<uint8_t> done(nb, 0);
+  {  // idle pooled contexts beyond what this call uses on a device give their memory back before the workers size their arenas
+    std::map<int, size_t> use;
+    for (size_t r = 0; r < n_dev; ++r) ++use[devices[r]];
+    for (auto &kv : use) pool_trim_device(kv.first, kv.second);
+  }
   struct Job { int rc = 0; zpaqhip_err err{}; long bad = -1; zpaqhip_stats st{}; };
   std::vector<Job> jobs(n_dev);
   auto worker = [&](size_t r) {

@@ -83,6 +83,7 @@ struct alignas(16) C2LdsT {
   uint32_t mixst[HELP == 1 ? 2 : 1][16][16];       // the mixer rows for c8 = 1
   uint32_t mb_nib, mb_byte, mb_ready;         // A -> B: seq << 8 | first nibble / byte;  B -> A: seq whose staging is complete
   uint32_t mb_cmd, mb_ack, mb_model;          // A -> B: block start / end / exit
+#ifdef ZH_WITH_CHAIN3
   // three-wave form (zh_chain3.hip): model wave <-> decoder wave
   uint32_t mb_ack2, mb_block;                 // the model wave's acknowledgement; block index of the command
   uint32_t yv;                                // decoder -> model: bit sequence number << 8 | the last 8 decoded bits
@@ -94,6 +95,7 @@ struct alignas(16) C2LdsT {
   uint32_t mixrow8[MIXLDS ? 16 : 1][64];
   uint32_t mixblk[MIXLDS ? 2 : 1][MIXLDS ? 1792 : 1];
   uint32_t mb_blk;                            // helper -> decoder: byte sequence number << 1 | half of mixblk the next byte's block is in
+#endif
   uint32_t hreg[kHWords];
   uint8_t mreg[kMBytes];
   uint32_t r[256], pr[256];

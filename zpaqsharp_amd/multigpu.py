@@ -171,13 +171,15 @@ class ShardedJob:
     {status, out_len} of ALL blocks, all-gathered; the plaintext of a rank's shard stays in that rank's output buffer
     (block plan[r][j] at out_off[j])."""
 
-    def __init__(self, ctx, h_stream: np.ndarray, d_in, sc, plan, rank, dist=None, coll_dev=None):
+    def __init__(self, ctx, h_stream: np.ndarray, d_in, sc, plan, rank, dist=None, coll_dev=None, store=None):
         self.ctx, self.h_stream, self.d_in, self.sc = ctx, h_stream, d_in, sc
         self.stream_len = int(h_stream.size)
         self.plan, self.rank, self.dist, self.coll_dev = plan, rank, dist, coll_dev
         self.shard = plan[rank]
         self.costs = None                                   # filled on first use by decode_dynamic
         self._passes = 0
+        self.store = store                                  # key-value store the ranks share (default: the process group's)
+        self._job_id = None                                 # drawn by rank 0 on the first dynamic pass, broadcast to all
         self.pulled: List[List[int]] = []                   # chunks this rank took in the last dynamic pass
         self.kernel_ms = 0.0                                # kernel time of this rank's last pass (HIP events, summed over launches)
 
@@ -205,7 +207,7 @@ class ShardedJob:
         return cls(ctx, stream, d_in, sc, [list(range(sc.n_blocks))], 0)
 
     @classmethod
-    def from_parts(cls, ctx, part: np.ndarray, dist, dev, coll_dev=None):
+    def from_parts(cls, ctx, part: np.ndarray, dist, dev, coll_dev=None, store=None):
         """`part` = the consecutive piece of the shared stream this rank holds (whole blocks).  The pieces are
         all-gathered (RCCL on the GPU box), rank 0 scans the result and broadcasts the table."""
         import ctypes as C
@@ -240,7 +242,7 @@ class ShardedJob:
         d_in = torch.from_numpy(np.concatenate([h_stream, np.zeros(16, np.uint8)]))
         if dev is not None:                                  # dev None: CPU-only ranks (tests of the table / plan / gather logic)
             d_in = d_in.to(dev)
-        return cls(ctx, h_stream, d_in, sc, plan, rank, dist, coll_dev)
+        return cls(ctx, h_stream, d_in, sc, plan, rank, dist, coll_dev, store)
 
     def decode(self, d_out, out_off, out_cap, decode_fn=None, **opt) -> np.ndarray:
         """Decode this rank's shard into `d_out` (a device tensor); returns the [n_blocks, 2] table {status, out_len}
@@ -293,21 +295,39 @@ class ShardedJob:
             local[j, 1] = sum(int(r.out_len) for r in segs)
         return local
 
+    def _queue_store(self):
+        if self.store is None:
+            from torch.distributed import distributed_c10d as c10d
+            self.store = c10d._get_default_store()          # (torch has no public accessor for the default group's store)
+        return self.store
+
+    def _queue_key(self) -> str:
+        """Key of this pass's shared counter: unique per job AND per pass.  Two ShardedJobs on one process group must not
+        share a counter (the second would start at the first one's final value and hand out no chunk at all): rank 0
+        draws a job number from the store the first time, every rank receives it by broadcast."""
+        if self._job_id is None:
+            jid = np.zeros(1, np.int64)
+            if self.rank == 0:
+                jid[0] = int(self._queue_store().add("zpaqhip/jobs", 1))
+            self._job_id = int(broadcast_table(jid, self.dist, 0, self.coll_dev)[0])
+        return f"zpaqhip/queue/{self._job_id}/{self._passes}"
+
     def decode_dynamic(self, d_out, out_off, out_cap, counter=None, queue_blocks: int = 256, decode_fn=None, **opt) -> np.ndarray:
         """One pass over the whole stream with the ranks pulling chunks from the shared queue (module docstring).
         `out_off` / `out_cap` are indexed by GLOBAL block id and must be the same on every rank — a block lands at
         the same offset of whichever rank's `d_out` decodes it.  Returns the [n_blocks, 3] table {status, out_len,
         rank that decoded it}, gathered from all ranks.  `counter`: fetch_add provider shared by the ranks (default: a
-        StoreCounter on the process group's store, one key per pass)."""
+        StoreCounter on the job's store under a key that is new for every job and pass, deleted after the gather)."""
         if self.costs is None:
             self.costs = self._weights(self.sc, self.h_stream)
         self._passes += 1
+        own_key = None
         if counter is None:
             if self.dist is None:
                 counter = LocalCounter()
             else:
-                from torch.distributed import distributed_c10d as c10d
-                counter = StoreCounter(c10d._get_default_store(), f"zpaqhip/queue/{self._passes}")
+                own_key = self._queue_key()
+                counter = StoreCounter(self._queue_store(), own_key)
         q = WorkQueue(self.costs, counter, queue_blocks)
         n = self.sc.n_blocks
         mine = np.full((n, 3), -1, np.int64)
@@ -322,6 +342,11 @@ class ShardedJob:
         if self.dist is None:
             return mine
         allres = all_gather_table(mine, self.dist, self.coll_dev)          # [world, n, 3]: each block filled by exactly one rank
+        if own_key is not None and self.rank == 0:                          # every rank has left the queue: the counter can go
+            try:
+                self._queue_store().delete_key(own_key)
+            except Exception:                                               # a store without delete_key keeps a few bytes
+                pass
         owner = allres[:, :, 2].argmax(axis=0)                              # the rank whose row is not -1
         table = allres[owner, np.arange(n)]
         return table
