@@ -115,7 +115,8 @@ typedef struct zpaqhip_opts {
   uint32_t struct_size;       /* = sizeof(zpaqhip_opts) */
   uint32_t verify_sha1;       /* 1: check stored SHA-1 of every segment (Decompresser.cs:183-191 contract); hashed on the GPU */
   uint32_t max_concurrent;    /* blocks in flight per launch; 0 = auto (memory-bound) */
-  uint32_t kernel;            /* 0 auto; 1 force the generic (one-lane) kernel; 3 prefer the lane-per-component kernel;
+  uint32_t kernel;            /* 0 auto; 1 force the generic (one-lane) kernel; 2 / 6: single-CM blocks one / two per workgroup
+                                 (auto: two when a launch has more than 256 of them); 3 prefer the lane-per-component kernel;
                                  4 lane-per-component without model specialisation; 5 the run-time-level form of the
                                  lane-per-component kernel also for the built-in min/mid/max models (cross-check);
                                  7 / 8: ignored (= auto) by the product build; a library built with `make EXPERIMENTS=1` runs the
@@ -123,7 +124,7 @@ typedef struct zpaqhip_opts {
   uint64_t zpaql_budget;      /* runaway-program guard, per run() call: max ZPAQL instructions on the interpreter, max backward
                                  jumps in an ahead-of-time translated program (a translation checks where it can loop);
                                  0 = default (1<<32).  Exceeding it ends the block with ZPAQHIP_E_BUDGET */
-  uint64_t batch_blocks;      /* whole-stream forms: blocks per pipeline batch; 0 = default (at least 256 blocks and 32 MiB
+  uint64_t batch_blocks;      /* whole-stream forms: blocks per pipeline batch; 0 = default (at least 512 blocks and 32 MiB
                                  of coded bytes per batch, so that every CU has a block) */
   uint64_t queue_blocks;      /* zpaqhip_decompress_multi: blocks per pull from the shared work queue; 0 = default (256: one
                                  block per CU of the device that takes the chunk) */

@@ -1,5 +1,6 @@
 """One-off fuzzer for the two-wave single-CM kernel (not collected by pytest): random alphabets, run lengths,
-block sizes, shifts, segment structure; GPU output vs the oracle.  Usage: python tests/fuzz_l1.py [cases] [seed]"""
+block sizes, shifts, segment structure; GPU output vs the oracle.  Usage: python tests/fuzz_l1.py [cases] [seed] [kernel]
+(kernel 6: the two-blocks-per-workgroup form)"""
 import os
 import sys
 
@@ -39,6 +40,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     ctx = z.Context(0)
+    kernel = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     for case in range(cases):
         bits, shift = int(rng.integers(9, 23)), int(rng.integers(9, 20))
         m = zpaql.assemble(f"comp 0 0 0 0 1 0 cm {bits} {int(rng.integers(1, 256))} hcomp a<<= {shift} *d=a halt end")
@@ -55,7 +57,7 @@ def main():
         c.end_block()
         s = c.getvalue()
         want = b"".join(parts)
-        got = ctx.decompress(s, verify_sha1=True).tobytes()
+        got = ctx.decompress(s, verify_sha1=True, kernel=kernel).tobytes()
         assert got == want, (case, bits, shift, nseg, [len(p) for p in parts])
         print("case", case, "ok", bits, shift, nseg, len(want), flush=True)
     print("all", cases, "cases ok")

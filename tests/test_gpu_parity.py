@@ -99,8 +99,10 @@ def test_cm_models_with_other_shapes(ctx):
     assert ctx.decompress(s, verify_sha1=True).tobytes() == x
 
 
-def test_two_wave_cm_kernel_stress(ctx):
-    """zh_cm.hip's decoder/helper split: shift forms that use the assembly loop (K >= 9) and the C++ body (K < 9),
+@pytest.mark.parametrize("kernel", [0, 6])
+def test_two_wave_cm_kernel_stress(ctx, kernel):
+    """(kernel 6: the two-blocks-per-workgroup form, 32 LDS windows per block, that a launch of more than 256 blocks takes.)
+    zh_cm.hip's decoder/helper split: shift forms that use the assembly loop (K >= 9) and the C++ body (K < 9),
     wide tables (window ids beyond one byte), data that thrashes the 36-window LDS cache (evictions, write-backs,
     reloads), runs of one byte (every byte waits for the helper wave's update of the same window), and several
     segments per block (the section is left and re-entered)."""
@@ -118,7 +120,7 @@ def test_two_wave_cm_kernel_stress(ctx):
         m = zpaql.assemble(cfg)
         for data in (runs, rand, few, text):
             s = synth.compress_block(m, data)
-            assert ctx.decompress(s, verify_sha1=True).tobytes() == data, cfg
+            assert ctx.decompress(s, verify_sha1=True, kernel=kernel).tobytes() == data, cfg
     # the oracle agrees on one of each (keeps the CPU time of this test small)
     m = zpaql.assemble(cfgs[1])
     assert oracle.decompress(synth.compress_block(m, few[:40000])) == few[:40000]
@@ -135,7 +137,22 @@ def test_two_wave_cm_kernel_stress(ctx):
         c.end_segment(oracle.sha1(part))
     c.end_block()
     s = c.getvalue()
-    assert ctx.decompress(s, verify_sha1=True).tobytes() == b"".join(parts)
+    assert ctx.decompress(s, verify_sha1=True, kernel=kernel).tobytes() == b"".join(parts)
+
+
+def test_more_single_cm_blocks_than_cus_run_two_per_workgroup(ctx):
+    """A launch with more than 256 single-CM blocks puts two blocks on every workgroup (zh_decode_cm_x2: four wavefronts,
+    the read-only tables shared, 32 windows per block): 700 small blocks of text-like, x86-like and random plaintext —
+    evictions in every block —, each against the generator's plaintext and the stored SHA-1; 512 blocks in flight."""
+    nb = 700
+    plains = [synth.plain("TXR"[b % 3], b, 2000 + (b * 37) % 3000).tobytes() for b in range(nb)]
+    s = b"".join(synth.compress_block("l1", d) for d in plains)
+    got = ctx.decompress(s, verify_sha1=True).tobytes()
+    assert ctx.stats().concurrent == 512 and ctx.stats().kernel_kind == 2
+    assert got == b"".join(plains)
+    assert ctx.decompress(s, kernel=2).tobytes() == got and ctx.stats().concurrent == 256      # the one-block form agrees
+    small = b"".join(synth.compress_block("l1", d) for d in plains[:3])                        # forced on a launch of three blocks
+    assert ctx.decompress(small, verify_sha1=True, kernel=6).tobytes() == b"".join(plains[:3])
 
 
 @pytest.mark.parametrize("model", ["l1+lz77", "mid+lz77", "min+lz77"])

@@ -23,6 +23,7 @@
 
 extern "C" hipError_t zh_launch_generic(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
+extern "C" hipError_t zh_launch_cm_x2(const ZhLaunch *L, uint32_t grid, hipStream_t stream);   // two blocks per workgroup
 extern "C" hipError_t zh_launch_sha1(const uint8_t *data, const uint64_t *seg, uint32_t n_seg, uint32_t *digest, hipStream_t stream);
 extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof, int pcall);
 extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
@@ -365,6 +366,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
   // that mixes models fills the GPU with whatever blocks it has), else one region sized for the most demanding family,
   // used by one family after the other
   uint32_t slots_of[ZH_NFAM] = {};
+  bool cm_x2[ZH_NFAM] = {};
   uint64_t stride_of[ZH_NFAM], arena_need = 0, arena_sum = 0, arena_off[ZH_NFAM] = {};
   uint32_t n_fam = 0;
   for (auto &x : stride_of) x = 256;
@@ -373,8 +375,14 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     for (uint32_t k : groups[g]) stride_of[g] = std::max<uint64_t>(stride_of[g], models[bd[k].model].arena_bytes);
     uint64_t max_slots = mem_budget / stride_of[g];
     if (max_slots == 0) { set_err(err, ZPAQHIP_E_DEVICE_MEM, -1, -1, "Out of memory"); return ZPAQHIP_E_DEVICE_MEM; }
-    uint32_t want = opts.max_concurrent ? opts.max_concurrent : 256u;   // one wave per CU by default
+    uint32_t want = opts.max_concurrent ? opts.max_concurrent : 256u;   // one block per CU by default
+    // single-CM blocks beyond one per CU: two per workgroup (zh_decode_cm_x2: 32 LDS windows each instead of 64), so a stream
+    // of many blocks uses all four SIMDs of a CU; opts.kernel == 6 forces that form, 2 the one-block form (A/B runs, tests)
+    cm_x2[g] = g == ZH_FAM_CM1 && !getenv("ZPAQHIP_PROF") && opts.kernel != 2 &&
+               (opts.kernel == 6 || (!opts.max_concurrent && groups[g].size() > 256));
+    if (cm_x2[g]) want = opts.max_concurrent ? opts.max_concurrent : 512u;
     slots_of[g] = (uint32_t)std::min<uint64_t>({(uint64_t)want, max_slots, (uint64_t)groups[g].size()});
+    if (cm_x2[g]) { slots_of[g] = (slots_of[g] + 1u) & ~1u; if (slots_of[g] > max_slots) { slots_of[g] = (uint32_t)(max_slots & ~1ull); cm_x2[g] = slots_of[g] >= 2; if (!cm_x2[g]) slots_of[g] = 1; } }
     arena_need = std::max<uint64_t>(arena_need, slots_of[g] * stride_of[g]);
     arena_off[g] = arena_sum;
     arena_sum += (slots_of[g] * stride_of[g] + 255) & ~255ull;
@@ -435,6 +443,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
       P.has_store = true; P.store_launch = L; P.store_base = base_of[g]; P.store_count = groups[g].size(); P.store_slots = slots_of[g];
     }
     else if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, slots_of[g], stream));
+    else if (g == ZH_FAM_CM1 && cm_x2[g]) HIPCHK(zh_launch_cm_x2(&L, slots_of[g] / 2, stream));
     else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, slots_of[g], stream));
 #ifdef ZH_WITH_CHAIN3
     else if (g > ZH_FAM_CHAIN && zh_chain3_has(g - ZH_FAM_CHAIN) && (opts.kernel == 7 || opts.kernel == 8))   // decoder ‖ model ‖ helper wave: experiment build only
@@ -573,7 +582,7 @@ extern "C" int zpaqhip_decode_blocks_device(zpaqhip_ctx *c, const void *d_in, co
 // Whole-stream forms: a three-stage pipeline over batches of whole blocks
 //
 //   source (caller's buffer, or Reader-shaped callback read incrementally)
-//     -> scan a batch (>= 256 blocks when the stream has them)            host
+//     -> scan a batch (>= 512 blocks when the stream has them)            host
 //     -> H2D of the batch's bytes                                         stream s_in
 //     -> decode kernels (zh_* families)                                   stream c->stream
 //     -> D2H of the plaintext, block by block, into stream order          stream s_out
@@ -634,7 +643,7 @@ struct Sinkk {
   std::vector<std::vector<uint8_t>> *spill = nullptr;
 };
 
-constexpr size_t kBatchMinBlocks = 256, kBatchMinBytes = 32u << 20, kBatchMaxBlocks = 4096;
+constexpr size_t kBatchMinBlocks = 512, kBatchMinBytes = 32u << 20, kBatchMaxBlocks = 4096;   // 512: single-CM blocks run two per CU (zh_decode_cm_x2); the other kernels take the batch in two rounds of their work queue
 constexpr size_t kReadChunk = 4u << 20, kPinChunk = 32u << 20;
 
 // A header the framing scan accepts can still be refused when the model is built (component limits, table sizes:

@@ -251,8 +251,9 @@ __device__ constexpr uint32_t c2_units() {
 // become, and brings what byte s+1 will start with — h[], the three candidate hash rows of every ICM / ISSE for c8 = 1,
 // the mixer row — into LDS for each of them.  When A knows byte s it takes the matching column; B commits that
 // candidate's machine state.  B never decides anything: a late B only makes A wait.
-template <class SP, class LDS>
+template <class SP, class LDS, bool PROF = false>
 __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_block_slot) {
+  uint64_t hb_busy = 0, hb_slack = 0, hb_t0 = 0, hb_t1 = 0;   // PROF: nibble seen -> staging complete; staging complete -> byte seen
   constexpr bool ROWS = SP::helper == 1;                 // min / mid: rows and mixer weights staged in LDS too
   constexpr bool TOUCH = SP::helper == 2;                // max (no LDS left): HCOMP, and the lines of those rows pulled towards L2
   constexpr uint32_t NU = c2_units<SP>(), NH = 1u << SP::hh, RN = ROWS ? 2u : (NU + 3u) / 4u;
@@ -265,7 +266,14 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
     while ((cmd = c2_ld(&S.mb_cmd)) == seen_cmd) { __builtin_amdgcn_s_sleep(4); if (++sp > kC2Spin) return; }
     seen_cmd = cmd;
     if ((cmd & 3u) == kC2Exit) return;
-    if ((cmd & 3u) != kC2New) { c2_put0(&S.mb_ack, cmd); continue; }   // End: acknowledged once this wave has left the block (its last commit is in LDS)
+    if ((cmd & 3u) != kC2New) {
+      if (PROF && lane == 0 && L.debug) {
+        atomicAdd((unsigned long long *)&L.debug[14], (unsigned long long)hb_busy);
+        atomicAdd((unsigned long long *)&L.debug[15], (unsigned long long)hb_slack);
+      }
+      hb_busy = 0; hb_slack = 0;
+      c2_put0(&S.mb_ack, cmd); continue;
+    }   // End: acknowledged once this wave has left the block (its last commit is in LDS)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const ZhModel *M = &L.models[uni(c2_ld(&S.mb_model))];
     const uint32_t arena_bytes = uni((uint32_t)M->arena_bytes);
@@ -294,6 +302,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
     c2_put0(&S.mb_ack, cmd);
     uint32_t seq = 1;
     bool alive = true;
+    uint32_t touch_a = 0, touch_b[6] = {0, 0, 0, 0, 0, 0};   // results of the line touches (dropped; kept so that nothing waits for them early)
     while (alive) {
       // ---- the first nibble of byte #seq
       uint32_t v;
@@ -302,6 +311,8 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
         if (c2_ld(&S.mb_cmd) != seen_cmd || ++sp > kC2Spin) { alive = false; break; }
       }
       if (!alive) break;
+      if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hb_t0)::"memory"); }
+      asm volatile("" ::"v"(touch_a), "v"(touch_b[0]), "v"(touch_b[1]), "v"(touch_b[2]), "v"(touch_b[3]), "v"(touch_b[4]), "v"(touch_b[5]));   // the touches of the byte before are long back
       const uint32_t x = (v & 15u) << 4 | cand;
       // ---- HCOMP for the candidates (all 64 lanes run it: four copies of each candidate)
       uint32_t sa = x, sb = hb, sc = hc, sd = hd, sf = hf;
@@ -356,6 +367,16 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
           mwv[q][t] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, jj < SP::mix_m[q] ? row + jj * 4u : kOob, 0, 0);
         }
       }
+#ifdef C2_TOUCH
+      if (C2_TOUCH && SP::nmix > 0 && !LDS::kMixLds) {
+        // lines 0-3 of the block of mixer rows each candidate byte leads to (rows 1-15: what bits 0-3 of the next byte
+        // read); the rest of the winner's block is touched at the commit below.  The values are dropped, late.
+        uint32_t hq = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < NH; ++d) if ((SP::mix_lane[0] & (NH - 1u)) == d) hq = (uint32_t)sh[d];
+        touch_a = __builtin_amdgcn_raw_buffer_load_b32(rsrc, mx_base[0] + (hq & mx_size1[0] & ~255u) * (SP::mix_m[0] * 4u) + grp * 128u, 0, 0);
+      }
+#endif
 #pragma unroll
       for (uint32_t r = 0; r < 2; ++r) {
         if (u_on[r]) {
@@ -374,6 +395,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       }
       asm volatile("" ::: "memory");
       c2_put0(&S.mb_ready, seq);
+      if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hb_t1)::"memory"); hb_busy += hb_t1 - hb_t0; }
       if constexpr (TOUCH) {
         // The decoder wave will request the candidate's rows itself once the byte is known; one dword per (candidate,
         // component) now brings the 64-byte line that holds all three probes of Predictor.find (h0, h0^16, h0^32) out of
@@ -403,11 +425,33 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
         __builtin_amdgcn_s_sleep(1);                     // (nothing to do until the byte is known: poll gently)
       }
       if (!alive) break;
+      if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hb_t0)::"memory"); hb_slack += hb_t0 - hb_t1; }
       const uint32_t lo = v & 15u;
       hb = rdlane(sb, lo); hc = rdlane(sc, lo); hd = rdlane(sd, lo); hf = rdlane(sf, lo);
       const uint32_t cwi = rdlane(wi, lo), cwv = rdlane(wv, lo), cwn = rdlane(wn, lo);
       if (cwn && lane == 0) S.mreg[cwi] = (uint8_t)cwv;
       if (lane < NH) { const uint32_t hv_ = S.hspec[lane][lo]; S.hreg[lane] = hv_; }
+#ifdef C2_TOUCH
+      if (C2_TOUCH && SP::nmix > 0 && !LDS::kMixLds) {
+        // the byte is known, so is the block of 255 mixer rows the next byte walks (a new 128-byte line with almost every
+        // bit): one dword per line and lane now, and the decoder wave's one-bit-ahead requests find the lines in L2
+        const uint32_t hq = S.hspec[SP::mix_lane[0] & (NH - 1u)][lo];
+        const uint32_t b0 = mx_base[0] + (hq & mx_size1[0] & ~255u) * (SP::mix_m[0] * 4u);
+        constexpr uint32_t kBlk = 256u * SP::mix_m[0] * 4u;
+#pragma unroll
+        for (uint32_t t = 0; t < 2; ++t)
+          if (t * 8192u < kBlk) touch_b[t] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 128u + t * 8192u < kBlk ? b0 + lane * 128u + t * 8192u : kOob, 0, 0);
+        if constexpr (SP::has_tail) {                   // max: the 256 rows of `sse 16 19` under h[20] (32 entries = one line each)
+          const ZhComp &sc20 = M->comp[20];
+          const uint32_t h20 = S.hspec[20][lo];
+#pragma unroll
+          for (uint32_t t = 0; t < 4; ++t) {
+            const uint32_t r = (((h20 + lane + 64u * t) * 32u) & sc20.cm_mask) * 4u + (uint32_t)sc20.cm_off;
+            touch_b[2 + t] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, r, 0, 0);
+          }
+        }
+      }
+#endif
       if constexpr (LDS::kMixLds) {
         // the block of mixer rows the NEXT byte uses (its context is known now) -> the other half of mixblk; a byte
         // that keeps the context keeps the block, which the decoder wave has kept up to date

@@ -37,6 +37,25 @@ using namespace zhdev;
 
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 
+// Build-time variants for same-box A/B runs (tools/ab_bench.sh): make CXXFLAGS+=-DC2V=<mask>.  The shipped build is all on.
+//   1  the decoder step hands y to the vector side itself (select mask, ey, y made under the split's SCC: ZH_DEC_STEP_Y)
+//   2  what a bit trains but the NEXT bit cannot read — mixer weights (their row changes with every bit), max's SSE entries
+//      and `mix2 8` weight — is computed one bit later, in the shadow of that bit's squash look-up (an s_load or ds_read
+//      round trip during which round 3's wave issued nothing)
+//   4  the hash row of the nibble stays in four VGPRs: the bit histories of the next bit's two candidate nodes are bit
+//      fields of a register, not an LDS read in front of the entry reads
+//   8  the helper wave touches the lines of the mixer rows (and max's `sse 16` rows) a byte can reach before the decoder
+//      wave asks for them (zh_c2_common.h): the per-bit weight loads, requested one bit ahead, then hit L2 (~200 cycles)
+//      instead of HBM (~900) — round 4's stamps found the decoder wave waiting ~200 cycles per bit for them in mid
+//  16  (with 4) ONE-way entry fetch: the next bit's entry is read right after the bit is decoded (its state is a bit field of
+//      the row registers, its address one v_lshl_add) and comes back under the update's ~35 instructions; round 2/3 read
+//      both candidates before the bit was known and selected: 13 instructions against 6
+//  32  MATCH's prediction as pm0 + bit * (pm1 - pm0) and a miss resetting it to the lane's constant: 7 instructions for 10
+#ifndef C2V
+#define C2V 15
+#endif
+#define C2_TOUCH ((C2V & 8) != 0)
+
 #include "zh_c2_common.h"
 
 namespace {
@@ -67,6 +86,10 @@ __device__ __forceinline__ int mul24_sv(int sc, int vec) {
   return r;
 }
 
+
+constexpr bool kYsel = (C2V & 1) != 0, kDefer = (C2V & 2) != 0, kRowReg = (C2V & 4) != 0;
+constexpr bool kOneWay = (C2V & 16) != 0 && kRowReg, kMatch2 = (C2V & 32) != 0;
+
 template <class SP, bool PROF, int HELP, class LDS>
 __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
   uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -86,7 +109,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     if (lane == 0) { S.zrow = v4u_{0, 0, 0, 0}; S.mb_cmd = 0; S.mb_ack = 0; S.mb_nib = 0; S.mb_byte = 0; S.mb_ready = 0; }
   }
   __syncthreads();                                       // the only workgroup barrier of the kernel
-  if constexpr (HELP) { if (!wave_a) { c2_helper<SP>(L, S, lane, blockIdx.x); return; } }
+  if constexpr (HELP) { if (!wave_a) { c2_helper<SP, LDS, PROF>(L, S, lane, blockIdx.x); return; } }
   uint32_t cmd_seq = 0;                                  // commands issued to the helper wave
   const uint32_t *ps_tab = reinterpret_cast<const ZhTablesX *>(L.tables + 1)->ps;
   for (uint32_t i = lane; i < 256; i += 64) {            // the two predictions of a match of length i
@@ -276,6 +299,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     uint32_t hv = 0;                                    // h[lane] (Predictor.cs:469)
     uint32_t rowoff = 0;                                // arena offset of the hash row held in S.slot[lane]
     uint32_t row_x = 0;                                 // first dword of that row as it was when the nibble began
+    uint32_t row_q1 = 0, row_q2 = 0, row_q3 = 0;        // kRowReg: dwords 1-3 likewise (histories of nodes 4-15; zero in lanes without a table)
     bool rowvalid = false;
     uint32_t ea = tab;                                  // LDS address of the entry the current bit uses
     uint32_t st = 0;                                    // its bit-history state
@@ -284,7 +308,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     uint32_t mrow[2] = {0, 0};                          // buffer offset of this lane's weight in that row
     // MATCH (Predictor.cs:273-287, 382-411): the lane's Component fields
     uint32_t m_len = 0, m_ptr = 0, m_limit = 0, m_byte = 0;
-    int pm0 = 0, pm1 = 0;                               // stretch of -+dt2k[len] for this byte; 0 once the match has failed
+    int pm0 = kMatch2 ? pself : 0, pm1 = 0;             // stretch of -+dt2k[len] for this byte; 0 once the match has failed (kMatch2: see C2V)
     // What the byte boundary will want from HBM is requested half a byte early (match_prefetch, at bit 4): cm_pre is
     // the hash-index entry of the current h[i] (read when h[i] was set: nothing else writes the index before the next
     // boundary), va/vb the first 64 byte pairs of the candidate's verification, mbn/mbc the byte predicted by the
@@ -336,6 +360,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
       }
       const uint32_t pw = *(lds_u32_p)(lds_off(S.pm01) + m_len * 4u);      // m_len stays 0 in the other lanes
       pm0 = (int)(int16_t)(pw & 0xffffu); pm1 = (int)pw >> 16;
+      if (kMatch2) { pm1 = l_match ? pm1 - pm0 : 0; pm0 = l_match ? pm0 : pself; }   // difference form, see C2V
     };
 
     // Hash rows of the nibble that starts now (c8 == 1 or 16 <= c8 < 32), Predictor.find (Predictor.cs:550-567).
@@ -378,6 +403,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
       *(lds_u4_p)lds_off(&S.slot[lane]) = row;           // lanes without a hash table never read their slot
       rowoff = sel; rowvalid = true;
       row_x = l_ii ? row.x : 0u;                          // bytes 1-3: the histories of nodes 1, 2, 3 (no LDS round trip for them)
+      if (kRowReg) { row_q1 = l_ii ? row.y : 0u; row_q2 = l_ii ? row.z : 0u; row_q3 = l_ii ? row.w : 0u; }
     };
     auto rows_finish = [&](const Probe &pr, const v4u &old, uint32_t old_off, bool old_valid) __attribute__((always_inline)) {
       rows_finish2(pr, old, 0u, false, old, old_off, old_valid, false);
@@ -483,6 +509,45 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
           Probe spec[4];                                 // candidate rows of the second nibble
           v4u old1 = {0, 0, 0, 0}; uint32_t old1_off = 0; bool old1_valid = false;   // the first nibble's row as it was evicted
           l0_direct();
+          // kDefer: what bit k-1 left for bit k's squash shadow (Dq), see C2V
+          struct Dq {
+            int p, e, mw[2]; uint32_t mrow[2];
+            uint32_t sel18, ti18, c8, a19i, sel20, ti20; int dtv18, dtv20, p17, p18, w19, ey;
+          } dq = {};
+          auto mix_train = [&](int pp, int ee, const int (&mww)[2], const uint32_t (&mrr)[2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (uint32_t q = 0; q < SP::nmix; ++q) {     // MIX (Predictor.cs:427-439): error from the mixer lane
+              const int eq = mul24_sv((int)rdlane((uint32_t)ee, SP::mix_lane[q]), mx_rate[q]) >> 4;
+              const int nmw = med3i(mww[q] + ((__mul24(eq, pp) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
+              __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw, rsrc, mrr[q], 0, 0);
+            }
+          };
+          auto mix2_train = [&](int w, int rate, uint32_t ln, int ee, int pj_, int pk_) __attribute__((always_inline)) -> int {   // Predictor.cs:414-426
+            int vrate = rate;
+            asm volatile("" : "+v"(vrate));
+            const int er = mul24_sv((int)rdlane((uint32_t)ee, ln), vrate) >> 5;
+            w += (__mul24(er, pj_ - pk_) + (1 << 12)) >> 13;
+            return w < 0 ? 0 : w > 65535 ? 65535 : w;
+          };
+          auto sse_train = [&](uint32_t pn, int dtv, int eyy) __attribute__((always_inline)) -> uint32_t {                      // Predictor.train, :1031-1036 form
+            const uint32_t count = pn & 0x3ffu;
+            const int error = eyy - (int)(pn >> 17);
+            return pn + ((uint32_t)__mul24(error, dtv) & 0xFFFFFC00u) + (count < C2Max::sse_limit);   // |error| < 2^15, dt < 2^16: the low 32 bits are the reference's wrapping product
+          };
+          // the part of max's tail training that the next bit cannot read (rows / indices move with c8)
+          auto tail_train_late = [&](const Dq &t) __attribute__((always_inline)) {
+            if constexpr (SP::id == 3) {
+              const uint32_t n18 = sse_train(t.sel18, t.dtv18, t.ey);
+              *(lds_u32_p)(lds_off(S.sse18) + ((t.c8 & 255u) * 32u + t.ti18) * 4u) = n18;
+              const uint32_t nw19 = (uint32_t)mix2_train(t.w19, C2Max::rate19, 19, t.e, t.p17, t.p18);
+              *(lds_u16_p)(lds_off(S.a19) + t.a19i * 2u) = (uint16_t)nw19;
+              const uint32_t n20 = sse_train(t.sel20, t.dtv20, t.ey);
+              const uint32_t off = ((((t_h20 + t.c8) * 32u + t.ti20) & sse20_mask) * 4u) + sse20_base;
+              __builtin_amdgcn_raw_buffer_store_b32(n20, rsrc, lane == 0 ? off : kOob, 0, 0);
+            }
+          };
+          uint32_t rzw = 0;                              // kRowReg: dword 2 or 3 of the row, by the nibble's first bit
+          uint32_t y_prev = 0;                           // the bit before (wave-uniform)
 #pragma unroll
           for (int bit = 0; bit < 8; ++bit) {
             const bool pre_ii = (bit & 3) != 3;          // the next bit stays in this nibble: fetch both of its nodes
@@ -497,9 +562,19 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             }
             // ---- (a) requests for the NEXT bit, both ways
             if (SP::match_lane >= 0 && bit == 4) match_prefetch();
-            uint32_t ea0 = 0, ea1 = 0;
+            uint32_t ea0 = 0, ea1 = 0, st0 = 0, st1 = 0;
             v2u e0 = {0, 0}, e1 = e0;
-            if (pre_ii) pairS = (bit & 3) == 0 ? row_x >> 16 : (uint32_t)*(lds_u16_p)(rrow + 2u * hm);
+            if (pre_ii && !kOneWay) {
+              if (kRowReg) {
+                // nodes 2hm, 2hm+1: bytes of the row held in registers (hm = 1: bytes 2, 3; hm = 2, 3: dword 1; hm = 4..7: dword 2 / 3)
+                const uint32_t x = (bit & 3) == 0 ? row_x : (bit & 3) == 1 ? row_q1 : rzw;
+                const uint32_t sh = (bit & 3) == 0 ? 16u : y_prev * 16u;
+                st0 = __builtin_amdgcn_ubfe(x, sh, 8u);
+                st1 = __builtin_amdgcn_ubfe(x, sh + 8u, 8u);
+              } else {
+                pairS = (bit & 3) == 0 ? row_x >> 16 : (uint32_t)*(lds_u16_p)(rrow + 2u * hm);
+              }
+            }
             int mwc0[2] = {0, 0}, mwc1[2] = {0, 0};
             uint32_t mrow0[2] = {0, 0}, mrow1[2] = {0, 0};
             if (pre_mx) {
@@ -523,15 +598,17 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             int xs = pself;
             if (SP::match_lane >= 0) {                   // MATCH predicts the next bit of the byte it points at
               const uint32_t cbit = (m_byte >> (7 - bit)) & 1;
-              xs = l_match ? (cbit ? pm1 : pm0) : pself;
+              if (kMatch2) xs = __mul24((int)cbit, pm1) + pm0;       // pm1 holds the DIFFERENCE here; other lanes: pm0 = pself, pm1 = 0
+              else xs = l_match ? (cbit ? pm1 : pm0) : pself;
             }
             const int x = l_ii ? (int)eB : xs;
             const int cw0 = (int)eA & isse_m;
             const int cw1m = (int)((uint32_t)x << cshift);
             int p = x;
-            if (pre_ii) {                                // second half of (a): the two entries (their addresses came back)
-              ea0 = tab + (pairS & 255u) * 8u;
-              ea1 = tab + (pairS >> 8) * 8u;
+            if (pre_ii && !kOneWay) {                    // second half of (a): the two entries (their addresses came back)
+              if (!kRowReg) { st0 = pairS & 255u; st1 = pairS >> 8; }
+              ea0 = tab + st0 * 8u;
+              ea1 = tab + st1 * 8u;
               e0 = *(lds_u2_p)ea0;
               e1 = *(lds_u2_p)ea1;
             }
@@ -558,7 +635,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               p = lane == 15u ? p15 : p;
               p16 = med3i(((int)rdlane((uint32_t)t1, 15) + mul24_sv((int)rdlane((uint32_t)w1hi, 15), p15)) >> 8, -2048, 2047);
               // (weights < 2^17, predictions < 2^12, SSE entries >> 10 < 2^22, errors < 2^16: every product of this tail is exact
-              // in 24-bit multiplies, which are full rate where v_mul_lo_u32 is quarter rate)
+              // in 24-bit multiplies)
               p17 = (__mul24(w17, p15) + __mul24(65536 - w17, p16)) >> 16;   // MIX2 17 (Predictor.cs:291-301)
               auto sse = [&](int pin, uint32_t rowv, int &pout, uint32_t &sel, uint32_t &ti, int &dtv) __attribute__((always_inline)) {   // dtv: per-lane copy, made scalar in update()
                 int pq = pin + 992;                                          // SSE (Predictor.cs:327-340)
@@ -578,6 +655,11 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
                 const uint32_t wt = (uint32_t)pq & 63u, iq = (uint32_t)pq >> 6;                 // iq <= 30
                 const uint32_t ea18 = lds_off(S.sse18) + ((c8 & 255u) * 32u + iq) * 4u;
                 const uint32_t e0 = *(lds_u32_p)ea18, e1 = *(lds_u32_p)(ea18 + 4u);
+                if (kDefer && bit > 0) {                 // (the SSE 18 entry read: ~64 cycles before its data is back)
+                  __builtin_amdgcn_sched_barrier(0);
+                  mix_train(dq.p, dq.e, dq.mw, dq.mrow);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
                 p18 = (int)*(lds_i16_p)((uint32_t)(uintptr_t)lds_stretch + ((__umul24(e0 >> 10, 64u - wt) + __umul24(e1 >> 10, wt)) >> 13) * 2u);
                 sel18 = (wt >> 5) ? e1 : e0;
                 ti18 = iq + (wt >> 5);
@@ -606,25 +688,54 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               uint32_t pv4 = ((uint32_t)p << 2) + 8192u;       // (p + 2048) * 4, scaled on the vector side: the v_readlane feeds the s_load directly
               asm("" : "+v"(pv4));                             // (the compiler would move the arithmetic behind the v_readlane, onto the scalar unit)
               const uint32_t pso = rdlane(pv4, SP::final_lane);
-              asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(ps) : "s"(ps_tab), "s"(pso));
+              if (kDefer) asm volatile("s_load_dword %0, %1, %2" : "=s"(ps) : "s"(ps_tab), "s"(pso));
+              else asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(ps) : "s"(ps_tab), "s"(pso));
             }
             const int sqp = (int)*(lds_u16_p)((uint32_t)(uintptr_t)lds_squash + (uint32_t)(p + 2048) * 2u);
+            const int pj = shr1(p);                        // ISSE update: the prediction of the component before (y-independent)
+            if (kDefer) {
+              // the look-up is on its way (s_load ~80 cycles, ds_read ~64 + a v_readlane): the wave spends them on the
+              // training the bit before left over
+              __builtin_amdgcn_sched_barrier(0);
+              if (bit > 0) {
+                if (SP::id != 3) mix_train(dq.p, dq.e, dq.mw, dq.mrow);
+                tail_train_late(dq);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              if (SP::smem_ps) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ps));
+            }
             if (!SP::smem_ps && SP::id == 3) {           // (squash * 2 + 1) << 16 on the vector side (max +0.3 %; min -0.3 %: not there)
               uint32_t psv = ((uint32_t)sqp << 17) | 0x10000u;
               asm("" : "+v"(psv));
               ps = rdlane(psv, SP::final_lane);
             } else if (!SP::smem_ps) ps = (rdlane((uint32_t)sqp, SP::final_lane) * 2 + 1) << 16;
             uint32_t jb = j, xr;
-            ZH_DEC_STEP_LITE(d, ps, jb, xr);
+            uint64_t ym = 0;
+            uint32_t ey_s = 0, y = 0;
+            if (kYsel) ZH_DEC_STEP_Y(d, ps, jb, xr, ym, ey_s, y);
+            else ZH_DEC_STEP_LITE(d, ps, jb, xr);
             j = jb;
             if (UNLIKELY(xr < 0x1000000u)) {
               const uint32_t was = bad;
               uint32_t later = 0;                         // after the byte's last bit the next EOS step re-checks by itself
               if (dec_renorm_chk(d, in, lane, bit == 7 ? later : bad) && !err) err = was ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF;
             }
-            const uint32_t y = uni(j & 1);
-            const int ey = y ? 32767 : 0;
+            if (!kYsel) { y = uni(j & 1); ey_s = y ? 32767u : 0u; }
+            const int ey = (int)ey_s;
+            auto pick = [&](uint32_t a0, uint32_t a1) __attribute__((always_inline)) -> uint32_t { return kYsel ? sel_y(a0, a1, ym) : (y ? a1 : a0); };
             C2_STAMP(2);
+            uint32_t nea1 = 0, st_n1 = 0;
+            v2u en1 = {0, 0};
+            if (kOneWay && pre_ii) {
+              // the next bit's node is 2hm + y: its bit-history state is byte (2 + y | 2 y' + y) of the row dword for this depth;
+              // the entry it selects is requested NOW (before this bit's entry is written back: the `same` test below serves
+              // that case from registers) and travels under the update
+              const uint32_t xr_ = (bit & 3) == 0 ? row_x : (bit & 3) == 1 ? row_q1 : rzw;
+              const uint32_t sh = ((bit & 3) == 0 ? 16u : y_prev * 16u) + y * 8u;
+              st_n1 = __builtin_amdgcn_ubfe(xr_, sh, 8u);
+              nea1 = tab + st_n1 * 8u;
+              en1 = *(lds_u2_p)nea1;
+            }
             // ---- (e) update (Predictor.cs:363-461)
             const int e = ey - sqp;
             // bit history of this node: next(state, y) -> row byte
@@ -632,67 +743,73 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             // ICM (Predictor.cs:375-381) and ISSE (:440-449), every lane computes both
             const uint32_t ncm = eA + (uint32_t)((int)(ey - (int)(eA >> 8)) >> 2);
             const int npst = *(lds_i16_p)((uint32_t)(uintptr_t)lds_stretch + ((ncm >> 7) & 0x1fffeu));
-            const int pj = shr1(p);
             const int nw0 = med3i((int)eA + ((__mul24(e, pj) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
             const int nw1 = med3i((int)eB + ((e + 16) >> 5), -(1 << 19), (1 << 19) - 1);
+            if (kDefer) {
+              dq.p = p; dq.e = e; dq.ey = ey;
 #pragma unroll
-            for (uint32_t q = 0; q < SP::nmix; ++q) {     // MIX (Predictor.cs:427-439): error from the mixer lane
-              const int eq = mul24_sv((int)rdlane((uint32_t)e, SP::mix_lane[q]), mx_rate[q]) >> 4;
-              const int nmw = med3i(mw[q] + ((__mul24(eq, p) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
-              __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw, rsrc, mrow[q], 0, 0);
-            }
+              for (uint32_t q = 0; q < SP::nmix; ++q) { dq.mw[q] = mw[q]; dq.mrow[q] = mrow[q]; }
+            } else mix_train(p, e, mw, mrow);
             if constexpr (SP::id == 3) {
-              auto mix2_train = [&](int w, int rate, uint32_t ln, int pj_, int pk_) __attribute__((always_inline)) -> int {   // Predictor.cs:414-426
-                int vrate = rate;
-                asm volatile("" : "+v"(vrate));
-                const int er = mul24_sv((int)rdlane((uint32_t)e, ln), vrate) >> 5;
-                w += (__mul24(er, pj_ - pk_) + (1 << 12)) >> 13;
-                return w < 0 ? 0 : w > 65535 ? 65535 : w;
-              };
-              auto sse_train = [&](uint32_t pn, int dtv) __attribute__((always_inline)) -> uint32_t {                      // Predictor.train, :1031-1036 form
-                const uint32_t count = pn & 0x3ffu;
-                const int error = ey - (int)(pn >> 17);
-                return pn + ((uint32_t)__mul24(error, dtv) & 0xFFFFFC00u) + (count < C2Max::sse_limit);   // |error| < 2^15, dt < 2^16: the low 32 bits are the reference's wrapping product
-              };
-              w17 = mix2_train(w17, C2Max::rate17, 17, p15, p16);
-              const uint32_t n18 = sse_train(sel18, dtv18);
-              *(lds_u32_p)(lds_off(S.sse18) + ((c8 & 255u) * 32u + ti18) * 4u) = n18;
-              w19 = (uint32_t)mix2_train((int)w19, C2Max::rate19, 19, p17, p18);
-              *(lds_u16_p)(lds_off(S.a19) + a19i * 2u) = (uint16_t)w19;
-              const uint32_t n20 = sse_train(sel20, dtv20);
-              {
-                const uint32_t off = ((((t_h20 + c8) * 32u + ti20) & sse20_mask) * 4u) + sse20_base;
-                __builtin_amdgcn_raw_buffer_store_b32(n20, rsrc, lane == 0 ? off : kOob, 0, 0);
+              w17 = mix2_train(w17, C2Max::rate17, 17, e, p15, p16);
+              if (kDefer) {
+                dq.sel18 = sel18; dq.ti18 = ti18; dq.dtv18 = dtv18; dq.c8 = c8; dq.a19i = a19i; dq.w19 = (int)w19;
+                dq.p17 = p17; dq.p18 = p18; dq.sel20 = sel20; dq.ti20 = ti20; dq.dtv20 = dtv20;
+              } else {
+                Dq now_{};
+                now_.e = e; now_.ey = ey; now_.sel18 = sel18; now_.ti18 = ti18; now_.dtv18 = dtv18; now_.c8 = c8; now_.a19i = a19i; now_.w19 = (int)w19;
+                now_.p17 = p17; now_.p18 = p18; now_.sel20 = sel20; now_.ti20 = ti20; now_.dtv20 = dtv20;
+                tail_train_late(now_);
               }
-              w21 = mix2_train(w21, C2Max::rate21, 21, p19, p20);
+              w21 = mix2_train(w21, C2Max::rate21, 21, e, p19, p20);
             }
             if (SP::match_lane >= 0) {                   // MATCH (Predictor.cs:383-384): a miss ends the match
               const uint32_t cbit = (m_byte >> (7 - bit)) & 1;
               const bool miss = cbit != y;
-              m_len = miss ? 0u : m_len; pm0 = miss ? 0 : pm0; pm1 = miss ? 0 : pm1;
+              if (kMatch2) { m_len = miss ? 0u : m_len; pm0 = miss ? pself : pm0; pm1 = miss ? 0 : pm1; }   // (pself is 0 in the MATCH lane; m_byte and pm1 are 0 elsewhere)
+              else { m_len = miss ? 0u : m_len; pm0 = miss ? 0 : pm0; pm1 = miss ? 0 : pm1; }
             }
             const uint32_t nA = l_isse ? (uint32_t)nw0 : ncm, nB = l_isse ? (uint32_t)nw1 : (uint32_t)npst;
             *(lds_u2_p)ea = v2u{nA, nB};
             *(lds_u8_p)(wrow + (hm & wrow_mask)) = (uint8_t)nsb;
             C2_STAMP(3);
             // ---- (f) bookkeeping (Predictor.cs:463-474) and hand-over to the next bit
+            if (PROF && ((C2_PROF_MASK >> 13) & 1) && pre_mx && SP::nmix > 0) {   // diagnostic: how long the next bit's weights (requested at this bit's start) are still away
+              C2_STAMP(13);
+              __builtin_amdgcn_sched_barrier(0);
+              if (SP::id == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // (younger than the loads: two weight stores and the SSE 20 store — this bit's, or kDefer: the bit before's)
+              else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+              __builtin_amdgcn_sched_barrier(0);
+              C2_STAMP(14);
+            }
             c8 = c8 * 2u + y;
             if (pre_mx) {
 #pragma unroll
-              for (uint32_t q = 0; q < SP::nmix; ++q) { mw[q] = y ? mwc1[q] : mwc0[q]; mrow[q] = y ? mrow1[q] : mrow0[q]; }
+              for (uint32_t q = 0; q < SP::nmix; ++q) { mw[q] = (int)pick((uint32_t)mwc0[q], (uint32_t)mwc1[q]); mrow[q] = pick(mrow0[q], mrow1[q]); }
             }
             if (SP::has_tail && pre_mx) {
               row20 = row20n;
-              w19 = y ? w19n1 : w19n0; a19i = c8 & 255u;
+              w19 = pick(w19n0, w19n1); a19i = c8 & 255u;
             }
-            if (pre_ii) {
+            if (pre_ii && kOneWay) {
               hm = hm * 2u + y;
-              const uint32_t nea = y ? ea1 : ea0;
+              const bool same = nea1 == ea;              // bit k trained the entry bit k+1 predicts from
+              st = st_n1;
+              eA = same ? nA : en1.x;
+              eB = same ? nB : en1.y;
+              ea = nea1;
+              if ((bit & 3) == 0) rzw = pick(row_q2, row_q3);
+            } else if (pre_ii) {
+              hm = hm * 2u + y;
+              const uint32_t nea = pick(ea0, ea1);
               const bool same = nea == ea;               // bit k trained the entry bit k+1 predicts from
-              st = y ? pairS >> 8 : pairS & 255u;
-              eA = same ? nA : (y ? e1.x : e0.x);
-              eB = same ? nB : (y ? e1.y : e0.y);
+              st = pick(st0, st1);
+              uint32_t cA = pick(e0.x, e1.x), cB = pick(e0.y, e1.y);
+              if (kYsel) asm volatile("" : "+v"(cA), "+v"(cB));      // (made here: the compiler would sink the two selects into a branch over `same`)
+              eA = same ? nA : cA;
+              eB = same ? nB : cB;
               ea = nea;
+              if (kRowReg && (bit & 3) == 0) rzw = pick(row_q2, row_q3);
             } else if (bit == 3) {
               // ---- second nibble (Predictor.cs:267-270: c8 & 0xf0 == 16): new rows, requested two bits ago
               v4u old; uint32_t old_off; bool old_valid;
@@ -700,12 +817,12 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               old1 = old; old1_off = old_off; old1_valid = old_valid;
               // The helper wave is told the first nibble: it now prepares the next byte for the 16 values this one can
               // still take.  What its loads must see of this wave's stores — the last byte boundary's row write-back, the
-              // c8 = 1 mixer row written at bit 0 — has reached memory by now: vector memory operations complete in issue
-              // order, and the value published here depends on data requested after those stores (mid, max: bit 3's
-              // decision went through mixer weights loaded at bit 2; min has no such load and publishes below, after
-              // rows_finish has consumed the rows requested at bit 1).  The two hash rows this wave writes later — the one
-              // just evicted and the second nibble's at the byte's end — are patched in from the copies kept here
-              // (old1, old) when the staged rows are taken.
+              // c8 = 1 mixer row written at bit 0 (kDefer: in bit 1's shadow) — has reached memory by now: vector memory
+              // operations complete in issue order, and the value published here depends on data requested after those
+              // stores (mid, max: bit 3's decision went through mixer weights loaded at bit 2; min has no such load and
+              // publishes below, after rows_finish has consumed the rows requested at bit 1).  The two hash rows this wave
+              // writes later — the one just evicted and the second nibble's at the byte's end — are patched in from the
+              // copies kept here (old1, old) when the staged rows are taken.
               if (HELP && SP::nmix > 0) c2_put0(&S.mb_nib, bseq << 8 | (c8 & 15u));
               switch (c8 & 3u) {                         // wave-uniform: four copies of the selection code, no data selects
                 case 0: rows_finish(spec[0], old, old_off, old_valid); break;
@@ -725,7 +842,12 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
 #pragma unroll
               for (uint32_t k = 0; k < 4; ++k) rows_issue(c8 * 4u + k, spec[k]);
             }
+            y_prev = y;
             C2_STAMP(8);
+          }
+          if (kDefer) {                                  // the last bit's left-over training (its rows are not the next byte's)
+            if (SP::nmix > 0) mix_train(dq.p, dq.e, dq.mw, dq.mrow);
+            tail_train_late(dq);
           }
           if (UNLIKELY(err | bad)) { status = err ? -(int)err : ZH_E_CORRUPT; break; }
           c = (int)(c8 - 256);

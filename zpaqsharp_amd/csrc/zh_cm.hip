@@ -45,7 +45,6 @@ using namespace zhdev;
 
 namespace {
 
-constexpr uint32_t kWin = 64;             // LDS-resident windows: one tag per lane of wave A
 constexpr uint32_t kNoWin = 0xFFFFFFFFu;
 constexpr uint32_t kRing = 16;            // A -> B message ring (entries)
 enum : uint32_t { kMsgByte = 0, kMsgMiss = 1, kMsgLeave = 2 };
@@ -54,14 +53,23 @@ constexpr uint32_t kSpinSection = 1u << 27;   // bounded waits: nothing may hang
 constexpr uint64_t kSpinIdle = 1ull << 33;
 #define ZH_E_HELPER (-24)                  // = ZPAQHIP_E_HIP: the helper wavefront stopped answering (cannot happen by design)
 
-struct alignas(64) CmLds {
+// The model-independent tables (read-only after the kernel's one barrier) are shared by every block of the workgroup;
+// everything else belongs to ONE block: its window cache, its mailboxes, its cold machine state.  A workgroup holds one
+// block (NW = 64 windows, two wavefronts: zh_decode_cm) or — when a launch has more blocks than the GPU has CUs — two
+// (NW = 32 windows each, four wavefronts: zh_decode_cm_x2), so that an archive of many blocks fills more than one SIMD
+// pair of every CU.
+struct alignas(64) CmTabs {
   int16_t sh[16384];                      // stretch(x) for x in [16384, 32768); stretch(x) = -stretch(32767 - x) below
   uint16_t sq[4096];                      // squash
   int32_t dt[1024];
-  uint32_t winB[kWin][256];               // CM entries of groups 16..31 of the resident windows (second nibble)
-  uint32_t winA[kWin][16];                // CM entries of group 0 (first nibble)
-  uint16_t p16B[kWin][256];               // predict()*2+1 of every winB entry, order p16b_pos; kept current by wave B
-  uint16_t p16A[kWin][16];                // same for winA
+};
+template <uint32_t NW>
+struct alignas(64) CmBlkT {
+  static constexpr uint32_t kNW = NW;
+  uint32_t winB[NW][256];                 // CM entries of groups 16..31 of the resident windows (second nibble)
+  uint32_t winA[NW][16];                  // CM entries of group 0 (first nibble)
+  uint16_t p16B[NW][256];                 // predict()*2+1 of every winB entry, order p16b_pos; kept current by wave B
+  uint16_t p16A[NW][16];                  // same for winA
   alignas(64) uint32_t ring[kRing];       // A -> B messages: tag(7) | type(2) | byte(8) | 0(9) | slot(6); 64-byte aligned (zh_cm_fast.h steps the address with v_bfi)
   uint32_t dummy[64];                     // where the lanes of wave A other than lane 0 put their copy of a message (no exec switch)
   uint32_t aux[kRing][2];                 // MISS: new window, victim window
@@ -74,7 +82,12 @@ struct alignas(64) CmLds {
   Vm pz;                                  // cold machine state lives here, not in registers
   Sink sink;                              // output of a PCOMP program
 };
-static_assert(sizeof(CmLds) <= 163840, "LDS budget");
+template <uint32_t NW, uint32_t NP>
+struct alignas(64) CmLdsT {
+  CmTabs T;
+  CmBlkT<NW> B[NP];
+};
+static_assert(sizeof(CmLdsT<64, 1>) <= 163840 && sizeof(CmLdsT<32, 2>) <= 163840, "LDS budget");
 
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -109,24 +122,26 @@ static_assert(kRing == 16, "ring_tag");
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
 // predict()*2+1 for a CM entry: squash(stretch(cm >> 17)) (Predictor.cs:263-266, :349) through the half stretch table
-__device__ __forceinline__ uint32_t p16_of(const CmLds &S, uint32_t cm) {
+__device__ __forceinline__ uint32_t p16_of(const CmTabs &T, uint32_t cm) {
   const uint32_t xv = cm >> 17;
-  const int st = xv >= 16384 ? (int)S.sh[xv - 16384] : -(int)S.sh[16383 - xv];
-  return (uint32_t)S.sq[st + 2048] * 2 + 1;
+  const int st = xv >= 16384 ? (int)T.sh[xv - 16384] : -(int)T.sh[16383 - xv];
+  return (uint32_t)T.sq[st + 2048] * 2 + 1;
 }
 
 // Window <-> table.  A window is 512 entries = 2 KiB of the reference table; this kernel only ever touches group 0
 // (uint4 0..3) and groups 16..31 (uint4 64..127) of it, so the 960 bytes in between are free: the HBM copy of a window
 // carries its probability cache there (p16A at uint4 4..5, p16B at uint4 8..39).  A window that comes back from HBM is
 // then usable at once — the miss path has no table walk (stretch, squash) for its 272 entries.
-__device__ __forceinline__ void win_store(const CmLds &S, uint32_t slot, uint32_t *table, uint32_t w, uint32_t lane) {
+template <class BLK>
+__device__ __forceinline__ void win_store(const BLK &S, uint32_t slot, uint32_t *table, uint32_t w, uint32_t lane) {
   uint4 *g = reinterpret_cast<uint4 *>(table + (uint64_t)w * 512);
   g[64 + lane] = reinterpret_cast<const uint4 *>(&S.winB[slot][0])[lane];
   if (lane < 4) g[lane] = reinterpret_cast<const uint4 *>(&S.winA[slot][0])[lane];
   if (lane < 32) g[8 + lane] = reinterpret_cast<const uint4 *>(&S.p16B[slot][0])[lane];
   if (lane >= 32 && lane < 34) g[4 + lane - 32] = reinterpret_cast<const uint4 *>(&S.p16A[slot][0])[lane - 32];
 }
-__device__ __forceinline__ void win_load(CmLds &S, uint32_t slot, const uint32_t *table, uint32_t w, uint32_t lane) {
+template <class BLK>
+__device__ __forceinline__ void win_load(BLK &S, uint32_t slot, const uint32_t *table, uint32_t w, uint32_t lane) {
   const uint4 *g = reinterpret_cast<const uint4 *>(table + (uint64_t)w * 512);
   const uint4 b = g[64 + lane];
   uint4 a = make_uint4(0, 0, 0, 0), p = a;
@@ -139,19 +154,22 @@ __device__ __forceinline__ void win_load(CmLds &S, uint32_t slot, const uint32_t
   if (lane >= 32 && lane < 34) reinterpret_cast<uint4 *>(&S.p16A[slot][0])[lane - 32] = p;
 }
 // probability cache of one slot from its entries (whole wave)
-__device__ __forceinline__ void p16_rebuild(CmLds &S, uint32_t slot, uint32_t lane) {
+template <class BLK>
+__device__ __forceinline__ void p16_rebuild(const CmTabs &T, BLK &S, uint32_t slot, uint32_t lane) {
 #pragma unroll
   for (uint32_t k = 0; k < 4; ++k) {
     const uint32_t e = lane + 64 * k;
-    S.p16B[slot][p16b_pos(e >> 4, e & 15)] = (uint16_t)p16_of(S, S.winB[slot][e]);
+    S.p16B[slot][p16b_pos(e >> 4, e & 15)] = (uint16_t)p16_of(T, S.winB[slot][e]);
   }
-  if (lane < 16) S.p16A[slot][lane] = (uint16_t)p16_of(S, S.winA[slot][lane]);
+  if (lane < 16) S.p16A[slot][lane] = (uint16_t)p16_of(T, S.winA[slot][lane]);
 }
 // Replacement: an empty slot if there is one, else the slot whose last use is oldest (lane s holds slot s's stamp).
+template <uint32_t NW>
 __device__ __forceinline__ uint32_t pick_victim(uint32_t tag, uint32_t lastuse, uint32_t now) {
-  const uint64_t empty = __ballot(tag == kNoWin);
+  constexpr uint64_t kSlots = NW >= 64 ? ~0ull : (1ull << (NW & 63)) - 1;   // lanes that stand for a slot (lane s = slot s)
+  const uint64_t empty = __ballot(tag == kNoWin) & kSlots;
   if (empty) return (uint32_t)__builtin_ctzll(empty);
-  const uint32_t age = now - lastuse;
+  const uint32_t age = (threadIdx.x & 63) < NW ? now - lastuse : 0u;
   // wave-wide maximum with DPP row shifts / row broadcasts (same shape as zhdev::wave_sum); lane 63 ends up with it
   uint32_t m = age;
   auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
@@ -162,14 +180,15 @@ __device__ __forceinline__ uint32_t pick_victim(uint32_t tag, uint32_t lastuse, 
   m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1,3
   m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2,3
   m = rdlane(m, 63);
-  return (uint32_t)__builtin_ctzll(__ballot(age == m));
+  return (uint32_t)__builtin_ctzll(__ballot(age == m) & kSlots);
 }
 
 // ---------------------------------------------------------------------------------------
 // Wave B: model trainer / probability cache / plaintext writer of the steady state.
 // ---------------------------------------------------------------------------------------
-template <bool PROF>
-__device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
+template <bool PROF, class BLK>
+__device__ void helper_wave(const ZhLaunch &L, const CmTabs &T, BLK &S, uint32_t lane) {
+  constexpr uint32_t kWin = BLK::kNW;
   uint64_t busy = 0, tb0 = 0, tb1 = 0, idle = 0;
   const uint32_t l15 = lane & 15;
   const uint32_t ltt = 31 - __clz((int)(l15 | 1));
@@ -196,7 +215,7 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
     ob.stored = uni64(S.ob_stored); ob.word = uni(S.ob_word); ob.room = uni(S.ob_room); ob.park = 0;
     for (uint32_t sl = 0; sl < kWin; ++sl) {               // usually one slot (the byte that names the post-processor)
       if (uni(S.tags[sl]) == 0) continue;
-      p16_rebuild(S, sl, lane);
+      p16_rebuild(T, S, sl, lane);
     }
     uint32_t u = uni(S.t0), sp = 0;                        // next message to take
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -227,10 +246,10 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
         const uint32_t eoff = second ? offB + slot * 1024 + n1 * 64 : offA + slot * 64;
         // every lane reads (harmless for the unvisited ones); only the writes are masked
         const uint32_t cm = *(lds_u32_p)eoff;                           // stage 1
-        const int shv = S.sh[stretch_idx(p_nv)];                        // stage 2 of the previous byte
+        const int shv = T.sh[stretch_idx(p_nv)];                        // stage 2 of the previous byte
         const uint32_t cnt = cm & 0x3ff;
-        const int dtv = S.dt[cnt];
-        const uint32_t sqv = S.sq[((p_nv >> 17) >= 16384 ? shv : -shv) + 2048];
+        const int dtv = T.dt[cnt];
+        const uint32_t sqv = T.sq[((p_nv >> 17) >= 16384 ? shv : -shv) + 2048];
         const uint32_t yy = (nib >> lsh_y) & 1;
         const int err = (int)(yy * 32767) - (int)(cm >> 17);            // Predictor.train (Predictor.cs:1031-1036)
         const uint32_t nv = cm + (((uint32_t)err * (uint32_t)dtv) & 0xFFFFFC00u) + (cnt < limit);
@@ -246,8 +265,8 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
         out_put(ob, c, lane);                              // PostProcessor PASS: the byte is the plaintext
         if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1)::"memory"); busy += tb1 - tb0; }
       } else if (pend) {                                   // nothing new: finish the outstanding byte
-        const int shv = S.sh[stretch_idx(p_nv)];
-        const uint32_t sqv = S.sq[((p_nv >> 17) >= 16384 ? shv : -shv) + 2048];
+        const int shv = T.sh[stretch_idx(p_nv)];
+        const uint32_t sqv = T.sq[((p_nv >> 17) >= 16384 ? shv : -shv) + 2048];
         if (p_vis) *(lds_u16_p)p_off = (uint16_t)(sqv * 2 + 1);
         lds_order();
         lds_put0(&S.b_seq, u);
@@ -294,26 +313,28 @@ __device__ void helper_wave(const ZhLaunch &L, CmLds &S, uint32_t lane) {
   }
 }
 
-template <bool PROF>
-__device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
+template <bool PROF, uint32_t NW, uint32_t NP>
+__device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP> &SS) {
   uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tprev = 0;
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 1, pair = threadIdx.x >> 7;   // a block = one pair of wavefronts
+  CmTabs &T = SS.T;
+  CmBlkT<NW> &S = SS.B[NP > 1 ? pair : 0];
 
   {  // model-independent tables -> LDS (both waves)
     const uint4 *s0 = reinterpret_cast<const uint4 *>(L.tables->stretch + 16384);
-    uint4 *d0 = reinterpret_cast<uint4 *>(S.sh);
-    for (uint32_t i = threadIdx.x; i < sizeof(S.sh) / 16; i += 128) d0[i] = s0[i];
+    uint4 *d0 = reinterpret_cast<uint4 *>(T.sh);
+    for (uint32_t i = threadIdx.x; i < sizeof(T.sh) / 16; i += 128 * NP) d0[i] = s0[i];
     const uint4 *s1 = reinterpret_cast<const uint4 *>(L.tables->squash);
-    uint4 *d1 = reinterpret_cast<uint4 *>(S.sq);
-    for (uint32_t i = threadIdx.x; i < sizeof(S.sq) / 16; i += 128) d1[i] = s1[i];
+    uint4 *d1 = reinterpret_cast<uint4 *>(T.sq);
+    for (uint32_t i = threadIdx.x; i < sizeof(T.sq) / 16; i += 128 * NP) d1[i] = s1[i];
     const uint4 *s2 = reinterpret_cast<const uint4 *>(L.tables->dt);
-    uint4 *d2 = reinterpret_cast<uint4 *>(S.dt);
-    for (uint32_t i = threadIdx.x; i < sizeof(S.dt) / 16; i += 128) d2[i] = s2[i];
-    if (threadIdx.x == 0) { S.cmd_seq = 0; S.cmd_code = 0; S.cmd_ack = 0; S.t0 = 0; S.b_seq = 0; }
+    uint4 *d2 = reinterpret_cast<uint4 *>(T.dt);
+    for (uint32_t i = threadIdx.x; i < sizeof(T.dt) / 16; i += 128 * NP) d2[i] = s2[i];
+    if ((threadIdx.x & 127) == 0) { S.cmd_seq = 0; S.cmd_code = 0; S.cmd_ack = 0; S.t0 = 0; S.b_seq = 0; }
   }
   __syncthreads();                                       // the only workgroup barrier of the kernel
-  if (wave == 1) { helper_wave<PROF>(L, S, lane); return; }
+  if (wave == 1) { helper_wave<PROF>(L, T, S, lane); return; }
   uint32_t cmd_seq = 0;                                  // commands issued to wave B so far
 
   // per-lane constants of the lane <-> table-entry mapping
@@ -327,7 +348,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
   const uint32_t ring_addr = lds_off(&S.ring[0]), bseq_addr = lds_off(&S.b_seq);
   const uint32_t dummy_addr = lds_off(&S.dummy[lane]), ring_step = lane == 0 ? 63u : 0u;   // see ZH_FAST_EPILOGUE
 
-  uint8_t *slot_mem = L.arena + (uint64_t)blockIdx.x * L.arena_stride;
+  uint8_t *slot_mem = L.arena + (uint64_t)(blockIdx.x * NP + pair) * L.arena_stride;   // the host sizes the arena for grid x NP slots
 
   for (;;) {
     uint32_t bi = 0;
@@ -354,7 +375,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
       uint4 *q = reinterpret_cast<uint4 *>(table);
       for (uint64_t i = lane; i < cm_bytes / 16; i += 64) q[i] = v;
       // ... and the probability cache every window carries in HBM (win_store): predict()*2+1 of a fresh entry
-      const uint32_t pv = p16_of(S, 0x80000000u), pp = pv | pv << 16;
+      const uint32_t pv = p16_of(T, 0x80000000u), pp = pv | pv << 16;
       const uint4 ppat = make_uint4(pp, pp, pp, pp);
       const uint64_t nwin = cm_bytes / 2048;
       for (uint64_t i = lane; i < nwin * 34; i += 64) {
@@ -441,10 +462,10 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
           uint32_t slot;
           if (LIKELY(hit != 0)) slot = (uint32_t)__builtin_ctzll(hit);
           else {                                        // swap the window in (wave A alone: nothing is in flight)
-            slot = uni(pick_victim(tag, lastuse, t));
+            slot = uni(pick_victim<NW>(tag, lastuse, t));
             const uint32_t old = rdlane(tag, slot);
             if (old != kNoWin) {
-              if (rdlane(stale, slot)) { p16_rebuild(S, slot, lane); wave_sync(); }   // trained here, cache not refreshed yet
+              if (rdlane(stale, slot)) { p16_rebuild(T, S, slot, lane); wave_sync(); }   // trained here, cache not refreshed yet
               win_store(S, slot, table, old, lane);
             }
             win_load(S, slot, table, w, lane);
@@ -462,9 +483,9 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
           uint32_t cmb[4], pb[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) cmb[k] = wb[ib0 + 64 * k];
-          const uint32_t pa = p16_of(S, cma) << 16;
+          const uint32_t pa = p16_of(T, cma) << 16;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) pb[k] = p16_of(S, cmb[k]) << 16;
+          for (int k = 0; k < 4; ++k) pb[k] = p16_of(T, cmb[k]) << 16;
           ZH_STAMP(2);
 
           // ---- first nibble: context j lives in lane j
@@ -508,7 +529,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
             const uint32_t yy = (nib >> lsh_y) & 1;
             const uint32_t cnt = cm & 0x3ff;
             const int e = (int)(yy * 32767) - (int)(cm >> 17);
-            const uint32_t nv = cm + (((uint32_t)e * (uint32_t)S.dt[cnt]) & 0xFFFFFC00u) + (cnt < limit);
+            const uint32_t nv = cm + (((uint32_t)e * (uint32_t)T.dt[cnt]) & 0xFFFFFC00u) + (cnt < limit);
             if (vis) { if (isb) wb[ib0 + 64 * kb] = nv; else wa[l15] = nv; }
           }
           ZH_STAMP(5);
@@ -595,7 +616,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
             const uint32_t w = (h0 & cm_mask) >> 9;
             const uint64_t hit = __ballot(tag == w);
             if (UNLIKELY(hit == 0)) {                     // window miss: wave B swaps the window in
-              const uint32_t vs = uni(pick_victim(tag, lastuse, t));
+              const uint32_t vs = uni(pick_victim<NW>(tag, lastuse, t));
               const uint32_t old = rdlane(tag, vs);
               tag = lane == vs ? w : tag;
               if (lane == 0) { uint32_t *q = S.aux[t & (kRing - 1)]; q[0] = w; q[1] = old; }
@@ -732,13 +753,20 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLds &S) {
 }  // namespace
 
 extern "C" __global__ __launch_bounds__(128) void zh_decode_cm(ZhLaunch L) {
-  __shared__ CmLds S;
-  decode_cm_body<false>(L, S);
+  __shared__ CmLdsT<64, 1> S;
+  decode_cm_body<false, 64, 1>(L, S);
+}
+
+// Two blocks per workgroup (four wavefronts, 32 windows per block): taken by the host when a launch has more blocks than
+// the GPU has CUs (zh_api.cpp), so that an archive of many blocks uses all four SIMDs of every CU.
+extern "C" __global__ __launch_bounds__(256) void zh_decode_cm_x2(ZhLaunch L) {
+  __shared__ CmLdsT<32, 2> S;
+  decode_cm_body<false, 32, 2>(L, S);
 }
 
 extern "C" __global__ __launch_bounds__(128) void zh_decode_cm_prof(ZhLaunch L) {
-  __shared__ CmLds S;
-  decode_cm_body<true>(L, S);
+  __shared__ CmLdsT<64, 1> S;
+  decode_cm_body<true, 64, 1>(L, S);
 }
 
 extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream) {
@@ -748,5 +776,11 @@ extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, uint32_t grid, hipStr
 
 extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, uint32_t grid, hipStream_t stream) {
   hipLaunchKernelGGL(zh_decode_cm, dim3(grid), dim3(128), 0, stream, *L);
+  return hipGetLastError();
+}
+
+// grid workgroups of two blocks each: the arena must hold 2 x grid slots
+extern "C" hipError_t zh_launch_cm_x2(const ZhLaunch *L, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL(zh_decode_cm_x2, dim3(grid), dim3(256), 0, stream, *L);
   return hipGetLastError();
 }

@@ -170,6 +170,39 @@ struct Dec { uint32_t low, high, curr; };
         : "scc");                                                                                   \
   } while (0)
 
+// The same step handing the decoded bit to the VECTOR side in the forms its update wants, made while SCC still holds
+// y = (curr <= mid): ym = y ? ~0 : 0 as an SGPR pair (the select mask of every v_cndmask that picks between the two
+// pre-fetched candidates of the next bit: sel_y below), ey = y ? 32767 : 0 (Predictor.cs:366 `y * 32767`), yy = y.
+// Round 3 let the compiler derive them from j afterwards: s_and, s_bfe_i32, s_and, s_cmp, s_cselect_b64 per bit.
+#define ZH_DEC_STEP_Y(d, ps, j, x, ym, ey, yy)                                                      \
+  do {                                                                                              \
+    uint32_t r_, off_, mid_, m1_;                                                                   \
+    asm volatile(                                                                                   \
+        "s_sub_u32 %[r], %[high], %[low]\n\t"                                                       \
+        "s_mul_hi_u32 %[off], %[r], %[p]\n\t"                                                       \
+        "s_add_u32 %[mid], %[low], %[off]\n\t"                                                      \
+        "s_add_u32 %[m1], %[mid], 1\n\t"                                                            \
+        "s_cmp_le_u32 %[curr], %[mid]\n\t"                                                          \
+        "s_cselect_b32 %[high], %[mid], %[high]\n\t"                                                \
+        "s_cselect_b32 %[low], %[low], %[m1]\n\t"                                                   \
+        "s_cselect_b64 %[ym_], -1, 0\n\t"                                                           \
+        "s_cselect_b32 %[ey_], 0x7fff, 0\n\t"                                                       \
+        "s_cselect_b32 %[yy_], 1, 0\n\t"                                                            \
+        "s_addc_u32 %[jj], %[jj], %[jj]\n\t"                                                        \
+        "s_xor_b32 %[xx], %[high], %[low]"                                                          \
+        : [low] "+s"(d.low), [high] "+s"(d.high), [curr] "+s"(d.curr), [jj] "+s"(j), [xx] "=s"(x),  \
+          [ym_] "=&s"(ym), [ey_] "=&s"(ey), [yy_] "=&s"(yy),                                        \
+          [r] "=&s"(r_), [off] "=&s"(off_), [mid] "=&s"(mid_), [m1] "=&s"(m1_)                      \
+        : [p] "s"(ps)                                                                               \
+        : "scc");                                                                                   \
+  } while (0)
+// a1 where the wave-uniform mask says 1, else a0 (one v_cndmask_b32 on the SGPR pair made by ZH_DEC_STEP_Y)
+__device__ __forceinline__ uint32_t sel_y(uint32_t a0, uint32_t a1, uint64_t ym) {
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a0), "v"(a1), "s"(ym));   // (not volatile: the scheduler places it; a select that waits for a load must not hold up the ones behind it)
+  return r;
+}
+
 // Renormalisation loop of Decoder.decode (Decoder.cs:148-156).  Returns 0 or ZH_E_EOF.
 __device__ __forceinline__ int dec_renorm(Dec &d, InBuf &in, uint32_t lane) {
   int rc = 0;
