@@ -51,6 +51,13 @@ using namespace zhdev;
 //      the row registers, its address one v_lshl_add) and comes back under the update's ~35 instructions; round 2/3 read
 //      both candidates before the bit was known and selected: 13 instructions against 6
 //  32  MATCH's prediction as pm0 + bit * (pm1 - pm0) and a miss resetting it to the lane's constant: 7 instructions for 10
+//  64  the 12 hash-row requests of the second nibble's candidates go out BEHIND the mixer weights of bit 3 instead of in front
+//      of them: vector memory returns in issue order, and round 4's per-bit stamps show mid's bit 2 waiting ~360 cycles for
+//      its two weight dwords queued behind those rows (profiles/r04/prof_vm_wait.txt); the rounding addend of the weight
+//      updates in a VGPR (a v_mad_i32_i24 whose ADDEND is an SGPR takes 8.3 cycles against 4.9: tools/ubench/sgpr_bench)
+// 128  (mid, with 1) the weights of bits 6 and 7 — rows 64-255 of the byte's block, a new line with every bit, the only ones
+//      round 4's per-bit stamps still find the wave waiting for (~95 cycles each) — are requested TWO bits ahead, four
+//      candidate rows each, and picked by the two bits decoded meanwhile
 #ifndef C2V
 #define C2V 15
 #endif
@@ -88,7 +95,7 @@ __device__ __forceinline__ int mul24_sv(int sc, int vec) {
 
 
 constexpr bool kYsel = (C2V & 1) != 0, kDefer = (C2V & 2) != 0, kRowReg = (C2V & 4) != 0;
-constexpr bool kOneWay = (C2V & 16) != 0 && kRowReg, kMatch2 = (C2V & 32) != 0;
+constexpr bool kOneWay = (C2V & 16) != 0 && kRowReg, kMatch2 = (C2V & 32) != 0, kRowsLate = (C2V & 64) != 0, kFar2 = (C2V & 128) != 0 && kYsel;
 
 template <class SP, bool PROF, int HELP, class LDS>
 __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
@@ -510,6 +517,8 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
           v4u old1 = {0, 0, 0, 0}; uint32_t old1_off = 0; bool old1_valid = false;   // the first nibble's row as it was evicted
           l0_direct();
           // kDefer: what bit k-1 left for bit k's squash shadow (Dq), see C2V
+          int rnd12 = 1 << 12;                           // the weight updates' rounding addend
+          if (kRowsLate) asm volatile("" : "+v"(rnd12));   // ... in a VGPR (C2V 64)
           struct Dq {
             int p, e, mw[2]; uint32_t mrow[2];
             uint32_t sel18, ti18, c8, a19i, sel20, ti20; int dtv18, dtv20, p17, p18, w19, ey;
@@ -518,7 +527,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
 #pragma unroll
             for (uint32_t q = 0; q < SP::nmix; ++q) {     // MIX (Predictor.cs:427-439): error from the mixer lane
               const int eq = mul24_sv((int)rdlane((uint32_t)ee, SP::mix_lane[q]), mx_rate[q]) >> 4;
-              const int nmw = med3i(mww[q] + ((__mul24(eq, pp) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
+              const int nmw = med3i(mww[q] + ((__mul24(eq, pp) + rnd12) >> 13), -(1 << 19), (1 << 19) - 1);
               __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw, rsrc, mrr[q], 0, 0);
             }
           };
@@ -526,7 +535,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             int vrate = rate;
             asm volatile("" : "+v"(vrate));
             const int er = mul24_sv((int)rdlane((uint32_t)ee, ln), vrate) >> 5;
-            w += (__mul24(er, pj_ - pk_) + (1 << 12)) >> 13;
+            w += (__mul24(er, pj_ - pk_) + rnd12) >> 13;
             return w < 0 ? 0 : w > 65535 ? 65535 : w;
           };
           auto sse_train = [&](uint32_t pn, int dtv, int eyy) __attribute__((always_inline)) -> uint32_t {                      // Predictor.train, :1031-1036 form
@@ -548,6 +557,8 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
           };
           uint32_t rzw = 0;                              // kRowReg: dword 2 or 3 of the row, by the nibble's first bit
           uint32_t y_prev = 0;                           // the bit before (wave-uniform)
+          uint64_t ym_prev = 0;                          // ... as a select mask
+          int far_w[2][2][4] = {};                       // kFar2: the four candidate rows of bits 6 and 7
 #pragma unroll
           for (int bit = 0; bit < 8; ++bit) {
             const bool pre_ii = (bit & 3) != 3;          // the next bit stays in this nibble: fetch both of its nodes
@@ -577,6 +588,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             }
             int mwc0[2] = {0, 0}, mwc1[2] = {0, 0};
             uint32_t mrow0[2] = {0, 0}, mrow1[2] = {0, 0};
+            const bool far2 = kFar2 && SP::id == 2;        // see C2V 128
             if (pre_mx) {
 #pragma unroll
               for (uint32_t q = 0; q < SP::nmix; ++q) {
@@ -584,9 +596,20 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
                 // instruction, whatever the source says about the operands' width
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(mrow0[q]) : "s"(c8), "v"(SP::mix_m[q] * 8u), "v"(mx_rb[q]));
                 mrow1[q] = mrow0[q] + SP::mix_m[q] * 4u;
-                mwc0[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, mrow0[q], 0, 0);
-                mwc1[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, mrow1[q], 0, 0);
+                if (!(far2 && bit >= 5)) {               // (bits 6 and 7: requested two bits ago)
+                  mwc0[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, mrow0[q], 0, 0);
+                  mwc1[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, mrow1[q], 0, 0);
+                }
+                if (far2 && (bit == 4 || bit == 5)) {    // rows 4 c8 .. 4 c8 + 3: what the bit after next can use
+                  const uint32_t r4 = mrow0[q] * 2u - mx_rb[q];            // mx_rb + 4 c8 * row bytes
+#pragma unroll
+                  for (uint32_t i = 0; i < 4; ++i) far_w[bit - 4][q][i] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, r4 + i * (SP::mix_m[q] * 4u), 0, 0);
+                }
               }
+            }
+            if (bit == 2 && kRowsLate && SP::nmix > 0) {   // (see C2V 64: behind this bit's weight requests; c8 is what it was at the end of bit 1)
+#pragma unroll
+              for (uint32_t k = 0; k < 4; ++k) rows_issue(c8 * 4u + k, spec[k]);
             }
             uint32_t row20n = 0, w19n0 = 0, w19n1 = 0;
             if (SP::has_tail && pre_mx) {
@@ -743,7 +766,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             // ICM (Predictor.cs:375-381) and ISSE (:440-449), every lane computes both
             const uint32_t ncm = eA + (uint32_t)((int)(ey - (int)(eA >> 8)) >> 2);
             const int npst = *(lds_i16_p)((uint32_t)(uintptr_t)lds_stretch + ((ncm >> 7) & 0x1fffeu));
-            const int nw0 = med3i((int)eA + ((__mul24(e, pj) + (1 << 12)) >> 13), -(1 << 19), (1 << 19) - 1);
+            const int nw0 = med3i((int)eA + ((__mul24(e, pj) + rnd12) >> 13), -(1 << 19), (1 << 19) - 1);
             const int nw1 = med3i((int)eB + ((e + 16) >> 5), -(1 << 19), (1 << 19) - 1);
             if (kDefer) {
               dq.p = p; dq.e = e; dq.ey = ey;
@@ -780,12 +803,19 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               if (SP::id == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // (younger than the loads: two weight stores and the SSE 20 store — this bit's, or kDefer: the bit before's)
               else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
               __builtin_amdgcn_sched_barrier(0);
-              C2_STAMP(14);
+              { const uint64_t t13 = tprev; C2_STAMP(14); prof[bit] += tprev - t13; }   // ... and by bit position (stages 0-6 of a build that stamps only 13 / 14)
             }
             c8 = c8 * 2u + y;
             if (pre_mx) {
 #pragma unroll
-              for (uint32_t q = 0; q < SP::nmix; ++q) { mw[q] = (int)pick((uint32_t)mwc0[q], (uint32_t)mwc1[q]); mrow[q] = pick(mrow0[q], mrow1[q]); }
+              for (uint32_t q = 0; q < SP::nmix; ++q) {
+                if (far2 && bit >= 5) {                  // the four rows requested at bit - 1, by that bit's y and this one's
+                  const int (&f4)[4] = far_w[bit - 5][q];
+                  const uint32_t lo = sel_y((uint32_t)f4[0], (uint32_t)f4[2], ym_prev), hi = sel_y((uint32_t)f4[1], (uint32_t)f4[3], ym_prev);
+                  mw[q] = (int)pick(lo, hi);
+                } else mw[q] = (int)pick((uint32_t)mwc0[q], (uint32_t)mwc1[q]);
+                mrow[q] = pick(mrow0[q], mrow1[q]);
+              }
             }
             if (SP::has_tail && pre_mx) {
               row20 = row20n;
@@ -835,14 +865,14 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               l0_direct();
               C2_STAMP(4);
             }
-            if (bit == 1) {
+            if (bit == 1 && !(kRowsLate && SP::nmix > 0)) {
               // Two bits of the first nibble are known: the second nibble's context is one of c8*4 .. c8*4+3.  The hash
               // rows of all four are requested now, so that the HBM round trip runs under bits 2 and 3 (a candidate
               // that coincides with the row still held in LDS is patched from it when the nibble ends: rows_finish).
 #pragma unroll
               for (uint32_t k = 0; k < 4; ++k) rows_issue(c8 * 4u + k, spec[k]);
             }
-            y_prev = y;
+            y_prev = y; ym_prev = ym;
             C2_STAMP(8);
           }
           if (kDefer) {                                  // the last bit's left-over training (its rows are not the next byte's)

@@ -47,7 +47,7 @@ namespace {
 
 constexpr uint32_t kNoWin = 0xFFFFFFFFu;
 constexpr uint32_t kRing = 16;            // A -> B message ring (entries)
-enum : uint32_t { kMsgByte = 0, kMsgMiss = 1, kMsgLeave = 2 };
+enum : uint32_t { kMsgByte = 0, kMsgMiss = 1, kMsgLeave = 2, kMsgMissAux = 3 };   // Miss: window id in bits 6-22; MissAux: window ids in aux[]
 enum : uint32_t { kCmdEnter = 1, kCmdExit = 3 };
 constexpr uint32_t kSpinSection = 1u << 27;   // bounded waits: nothing may hang the GPU
 constexpr uint64_t kSpinIdle = 1ull << 33;
@@ -74,10 +74,13 @@ struct alignas(64) CmBlkT {
   uint32_t dummy[64];                     // where the lanes of wave A other than lane 0 put their copy of a message (no exec switch)
   uint32_t aux[kRing][2];                 // MISS: new window, victim window
   uint32_t tags[64];                      // ENTER: slot s was trained by wave A alone since B last saw it (its p16 is stale)
+  uint32_t wtag[64];                      // ENTER: window held by slot s (wave B keeps its own copy of the directory from here on)
+  uint4 wsink[64];                        // where lanes that hold no part of a window put their LDS write during a swap (no exec switch)
   uint32_t t0, b_seq;                     // message count at section start / messages completed by B
   uint32_t cmd_seq, cmd_code, cmd_ack;    // A -> B commands outside a section
   uint32_t limit, ob_word, ob_room;
   uint64_t table, ob_base, ob_cap, ob_len, ob_stored;
+  uint32_t table_bytes;                   // size of the CM table (buffer descriptor of wave B's window swaps)
   uint32_t pr[256];                       // PCOMP R
   Vm pz;                                  // cold machine state lives here, not in registers
   Sink sink;                              // output of a PCOMP program
@@ -163,24 +166,15 @@ __device__ __forceinline__ void p16_rebuild(const CmTabs &T, BLK &S, uint32_t sl
   }
   if (lane < 16) S.p16A[slot][lane] = (uint16_t)p16_of(T, S.winA[slot][lane]);
 }
-// Replacement: an empty slot if there is one, else the slot whose last use is oldest (lane s holds slot s's stamp).
-template <uint32_t NW>
-__device__ __forceinline__ uint32_t pick_victim(uint32_t tag, uint32_t lastuse, uint32_t now) {
-  constexpr uint64_t kSlots = NW >= 64 ? ~0ull : (1ull << (NW & 63)) - 1;   // lanes that stand for a slot (lane s = slot s)
-  const uint64_t empty = __ballot(tag == kNoWin) & kSlots;
-  if (empty) return (uint32_t)__builtin_ctzll(empty);
-  const uint32_t age = (threadIdx.x & 63) < NW ? now - lastuse : 0u;
-  // wave-wide maximum with DPP row shifts / row broadcasts (same shape as zhdev::wave_sum); lane 63 ends up with it
-  uint32_t m = age;
-  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
-  m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x111, 0xf, 0xf, false));   // row_shr:1
-  m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x112, 0xf, 0xf, false));   // row_shr:2
-  m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x114, 0xf, 0xf, false));   // row_shr:4
-  m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x118, 0xf, 0xf, false));   // row_shr:8
-  m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1,3
-  m = mx(m, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2,3
-  m = rdlane(m, 63);
-  return (uint32_t)__builtin_ctzll(__ballot(age == m) & kSlots);
+// Replacement (round 4): the first slot whose last use is older than message `thr` — empty slots carry 0, lanes that stand
+// for no slot ~0 and are never taken; when no slot is that old the threshold moves up to 31 messages ago (at least one of
+// 32 slots was not used in 31 messages).  A handful of instructions where true LRU needed a wave-wide maximum; on the
+// x86-like generator it misses as rarely as LRU (20.7 % against 20.5 %; first-in-first-out: 27 %).  zh_cm_fast.h does the
+// same test inline and leaves to the C++ body only when the threshold has to move.
+__device__ __forceinline__ uint32_t pick_victim(uint32_t lastuse, uint32_t now, uint32_t &thr) {
+  uint64_t old = __ballot(lastuse < thr);
+  if (UNLIKELY(old == 0)) { thr = now > 31u ? now - 31u : 1u; old = __ballot(lastuse < thr); }
+  return (uint32_t)__builtin_ctzll(old);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -190,6 +184,7 @@ template <bool PROF, class BLK>
 __device__ void helper_wave(const ZhLaunch &L, const CmTabs &T, BLK &S, uint32_t lane) {
   constexpr uint32_t kWin = BLK::kNW;
   uint64_t busy = 0, tb0 = 0, tb1 = 0, idle = 0;
+  uint64_t mis_a = 0, mis_b = 0, mis_c = 0;             // PROF, per miss: message seen -> requests out; -> window data back; -> installed and reported
   const uint32_t l15 = lane & 15;
   const uint32_t ltt = 31 - __clz((int)(l15 | 1));
   const uint32_t lsh_vis = 4 - ltt, lsh_y = 3 - ltt;
@@ -210,6 +205,20 @@ __device__ void helper_wave(const ZhLaunch &L, const CmTabs &T, BLK &S, uint32_t
     // ---- ENTER: take over the window cache and the output
     uint32_t *table = reinterpret_cast<uint32_t *>(L.arena + uni64(S.table));   // offsets, so that accesses stay global_*
     const uint32_t limit = uni(S.limit);
+    // window swaps (round 4): buffer accesses with one offset per lane and the window's place as the scalar offset — lanes
+    // that hold no part of a window carry an offset beyond the table and are dropped, their LDS writes go to a sink: no
+    // exec-mask code, no 64-bit address arithmetic (the round-3 form spent ~680 cycles getting its requests out and ~430
+    // installing the data, against ~130 for the data to arrive: profiles/r04/stages_l1_miss.txt)
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(table, 0, (int)uni(S.table_bytes), 0x00020000);
+    uint32_t tagB = S.wtag[lane];                            // this wave's copy of the directory: lane s = window in slot s
+    constexpr uint32_t kDrop = 0x80000000u;
+    const uint32_t g_offB = (64u + lane) * 16u, g_offA = lane < 4 ? lane * 16u : kDrop,
+                   g_offP = lane < 32 ? (8u + lane) * 16u : lane < 34 ? (4u + lane - 32u) * 16u : kDrop;
+    const uint32_t l_sink = lds_off(&S.wsink[lane]);
+    const uint32_t l_cB = lds_off(&S.winB[0][0]) + lane * 16u;
+    const uint32_t l_cA = lane < 4 ? lds_off(&S.winA[0][0]) + lane * 16u : l_sink, l_mA = lane < 4 ? 64u : 0u;
+    const uint32_t l_cP = lane < 32 ? lds_off(&S.p16B[0][0]) + lane * 16u : lane < 34 ? lds_off(&S.p16A[0][0]) + (lane - 32u) * 16u : l_sink,
+                   l_mP = lane < 32 ? 512u : lane < 34 ? 32u : 0u;
     OutBuf ob;
     ob.base = L.out + uni64(S.ob_base); ob.cap = uni64(S.ob_cap); ob.len = uni64(S.ob_len);
     ob.stored = uni64(S.ob_stored); ob.word = uni(S.ob_word); ob.room = uni(S.ob_room); ob.park = 0;
@@ -274,35 +283,52 @@ __device__ void helper_wave(const ZhLaunch &L, const CmTabs &T, BLK &S, uint32_t
       } else if (!have) {
         if (PROF) ++idle;
         if (++sp > kSpinSection) return;
-      } else if (type == kMsgMiss) {
+      } else if (type == kMsgMiss || type == kMsgMissAux) {
         sp = 0;
-        const uint32_t neww = uni(S.aux[u & (kRing - 1)][0]), oldw = uni(S.aux[u & (kRing - 1)][1]);
-        {                                                  // request the new window first, write the victim back while it travels
-          const uint4 *g = reinterpret_cast<const uint4 *>(table + (uint64_t)neww * 512);
-          const uint4 nb = g[64 + lane];
-          uint4 na = make_uint4(0, 0, 0, 0), np = na;
-          if (lane < 4) na = g[lane];
-          if (lane < 32) np = g[8 + lane];                  // its probability cache travels with it (win_store)
-          if (lane >= 32 && lane < 34) np = g[4 + lane - 32];
-          if (oldw != kNoWin) win_store(S, slot, table, oldw, lane);
-          reinterpret_cast<uint4 *>(&S.winB[slot][0])[lane] = nb;
-          if (lane < 4) reinterpret_cast<uint4 *>(&S.winA[slot][0])[lane] = na;
-          if (lane < 32) reinterpret_cast<uint4 *>(&S.p16B[slot][0])[lane] = np;
-          if (lane >= 32 && lane < 34) reinterpret_cast<uint4 *>(&S.p16A[slot][0])[lane - 32] = np;
+        uint64_t tm0 = 0, tm1 = 0, tm2 = 0;
+        if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm0)::"memory"); }
+        uint32_t neww, oldw;
+        if (LIKELY(type == kMsgMiss)) { neww = (m0 >> 6) & 0x1FFFFu; oldw = rdlane(tagB, slot); }
+        else { neww = uni(S.aux[u & (kRing - 1)][0]); oldw = uni(S.aux[u & (kRing - 1)][1]); }
+        tagB = lane == slot ? neww : tagB;
+        typedef __attribute__((address_space(3))) uint4 *lds_u4_p;
+        const uint32_t aB = l_cB + slot * 1024u, aA = l_cA + slot * l_mA, aP = l_cP + slot * l_mP;
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) v4u *lds_v4_p;
+        // request the new window first (its probability cache travels with it: win_store), write the victim back while it travels
+        const uint32_t so_new = neww * 2048u;
+        const v4u nb = __builtin_amdgcn_raw_buffer_load_b128(trs, g_offB, so_new, 0);
+        const v4u na = __builtin_amdgcn_raw_buffer_load_b128(trs, g_offA, so_new, 0);
+        const v4u np = __builtin_amdgcn_raw_buffer_load_b128(trs, g_offP, so_new, 0);
+        if (oldw != kNoWin) {
+          const v4u vb = *(lds_v4_p)aB, va = *(lds_v4_p)aA, vp = *(lds_v4_p)aP;
+          const uint32_t so_old = oldw * 2048u;
+          __builtin_amdgcn_raw_buffer_store_b128(vb, trs, g_offB, so_old, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(va, trs, g_offA, so_old, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(vp, trs, g_offP, so_old, 0);
         }
+        if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm1)::"memory"); asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // the window's three loads are back (the victim's stores need not be)
+                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm2)::"memory"); mis_a += tm1 - tm0; mis_b += tm2 - tm1; }
+        *(lds_v4_p)aB = nb;
+        *(lds_v4_p)aA = na;
+        *(lds_v4_p)aP = np;
         ++u;
         // LDS data, then LDS flag, in program order (lds_order): no fence — a release fence here would also wait for the
         // victim's write-back, a full store round trip that wave A has no reason to sit through (only this wave ever
         // reads that window back, and its own memory operations stay in order)
         lds_order();
         lds_put0(&S.b_seq, u);
+        if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm0)::"memory"); mis_c += tm0 - tm2; }
       } else {                                             // LEAVE: hand the output state back
         out_flush(ob, lane);
         if (PROF && lane == 0 && L.debug) {
           atomicAdd((unsigned long long *)&L.debug[5], (unsigned long long)busy);
           atomicAdd((unsigned long long *)&L.debug[7], (unsigned long long)idle);
+          atomicAdd((unsigned long long *)&L.debug[13], (unsigned long long)mis_a);
+          atomicAdd((unsigned long long *)&L.debug[14], (unsigned long long)mis_b);
+          atomicAdd((unsigned long long *)&L.debug[15], (unsigned long long)mis_c);
         }
-        busy = 0; idle = 0;
+        busy = 0; idle = 0; mis_a = mis_b = mis_c = 0;
         if (lane == 0) { S.ob_len = ob.len; S.ob_stored = ob.stored; S.ob_word = ob.word; S.ob_room = ob.room; }
         ++u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -315,8 +341,9 @@ __device__ void helper_wave(const ZhLaunch &L, const CmTabs &T, BLK &S, uint32_t
 
 template <bool PROF, uint32_t NW, uint32_t NP>
 __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP> &SS) {
-  uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  uint64_t tprev = 0;
+  uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t tprev = 0, t_exit = 0, t_pub = 0;           // PROF: stamps of the miss path (asm loop left, miss published)
+  bool was_miss = false;
   const uint32_t lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 1, pair = threadIdx.x >> 7;   // a block = one pair of wavefronts
   CmTabs &T = SS.T;
   CmBlkT<NW> &S = SS.B[NP > 1 ? pair : 0];
@@ -391,7 +418,8 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
 
     uint32_t tag = kNoWin;                             // per-lane window directory: lane s = slot s
     uint32_t stale = 0;                                // per-lane: slot s was trained outside a two-wave section (p16 not current)
-    uint32_t lastuse = 0;                              // per-lane: value of t after the last byte / message that used slot s
+    uint32_t lastuse = lane < NW ? 0u : ~0u;           // per-lane: value of t after the last byte / message that used slot s (lanes beyond the slots: never a victim)
+    uint32_t thr = 1;                                  // replacement threshold (pick_victim)
     uint32_t t = 0;                                    // bytes decoded + window swaps so far = messages published to wave B
     uint32_t h0 = 0;                                   // h[0] = z.H(0)
 
@@ -462,7 +490,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
           uint32_t slot;
           if (LIKELY(hit != 0)) slot = (uint32_t)__builtin_ctzll(hit);
           else {                                        // swap the window in (wave A alone: nothing is in flight)
-            slot = uni(pick_victim<NW>(tag, lastuse, t));
+            slot = uni(pick_victim(lastuse, t, thr));
             const uint32_t old = rdlane(tag, slot);
             if (old != kNoWin) {
               if (rdlane(stale, slot)) { p16_rebuild(T, S, slot, lane); wave_sync(); }   // trained here, cache not refreshed yet
@@ -543,11 +571,13 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
           // ===== steady state: PASS post-processor (PostProcessor.cs:49-51), two wavefronts =====
           // hand the window cache and the output to wave B
           S.tags[lane] = stale;
+          S.wtag[lane] = tag;
           stale = 0;
           if (lane < kRing) S.ring[lane] = ((ring_tag(t) + 64) & 127) << 25;   // never the tag of messages t .. t+15
           out_flush(ob, lane);
           if (lane == 0) {
             S.table = (uint64_t)(reinterpret_cast<uint8_t *>(table) - L.arena); S.limit = limit;
+            S.table_bytes = (uint32_t)(cm_bytes > 0xFFFFF000ull ? 0xFFFFF000ull : cm_bytes);
             S.ob_base = (uint64_t)(ob.base - L.out); S.ob_cap = ob.cap; S.ob_len = ob.len; S.ob_stored = ob.stored;
             S.ob_word = ob.word; S.ob_room = ob.room;
             S.t0 = t; S.b_seq = t; S.cmd_code = kCmdEnter;
@@ -596,10 +626,18 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
               if (LIKELY(d.curr - d.low <= d.high - d.low)) {   // the loop's invariant (an out-of-range state is the C++ body's to report)
                 const uint32_t klim = uni(in.avail >= 40 ? in.avail - 40 : 0u);
                 uint32_t vr = lane == 0 ? ring_addr + (t & (kRing - 1)) * 4u : dummy_addr;
+                if (PROF) {
+                  if (was_miss) { prof[10] += f0 - t_pub; was_miss = false; }     // miss published -> back in the loop
+                  uint32_t sp_lo = 0, sp_hi = 0, nsp = 0;
+                  ZH_CM_FAST_LOOP_PROF(d.low, d.high, d.curr, in.k, t, h0, b_done, lastuse, code, klim, uni(win_bfe), uni(hshift),
+                                       vr, ring_step, bseq_addr, in.cur, tag, p_la, p_lb, uni(thr), sp_lo, sp_hi, nsp);
+                  prof[11] += (uint64_t)sp_hi << 32 | sp_lo; prof[12] += nsp;     // cycles / times wave A waited in the spin
+                } else {
                 ZH_CM_FAST_LOOP(d.low, d.high, d.curr, in.k, t, h0, b_done, lastuse, code, klim, uni(win_bfe), uni(hshift),
-                                vr, ring_step, bseq_addr, in.cur, tag, p_la, p_lb);
+                                vr, ring_step, bseq_addr, in.cur, tag, p_la, p_lb, uni(thr));
+                }
               } else code = 0;
-              if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(f1)::"memory"); prof[2] += f1 - f0; prof[3] += t - t_in; }
+              if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(f1)::"memory"); prof[2] += f1 - f0; prof[3] += t - t_in; t_exit = f1; }
               if (UNLIKELY(code)) { ev = kEvCorrupt; d.low = d.high = d.curr = 1; }   // the EOS test below ends the section
             }
             if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
@@ -615,13 +653,18 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
             // ---- the byte's window (before any coder state changes, so that a miss can simply start over)
             const uint32_t w = (h0 & cm_mask) >> 9;
             const uint64_t hit = __ballot(tag == w);
-            if (UNLIKELY(hit == 0)) {                     // window miss: wave B swaps the window in
-              const uint32_t vs = uni(pick_victim<NW>(tag, lastuse, t));
+            if (UNLIKELY(hit == 0)) {                     // window miss: wave B swaps the window in (the fast loop serves a miss itself
+              thr = uni(thr);                             // unless the replacement threshold has to move or the id is too wide for a message)
+              const uint32_t vs = uni(pick_victim(lastuse, t, thr));
               const uint32_t old = rdlane(tag, vs);
               tag = lane == vs ? w : tag;
-              if (lane == 0) { uint32_t *q = S.aux[t & (kRing - 1)]; q[0] = w; q[1] = old; }
-              publish(kMsgMiss << 23 | vs);
+              if (w < 0x20000u) publish(kMsgMiss << 23 | w << 6 | vs);
+              else {
+                if (lane == 0) { uint32_t *q = S.aux[t & (kRing - 1)]; q[0] = w; q[1] = old; }
+                publish(kMsgMissAux << 23 | vs);
+              }
               lastuse = lane == vs ? t : lastuse;
+              if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_pub)::"memory"); prof[8] += t_pub - t_exit; prof[9] += 1; was_miss = true; }   // loop left -> miss published; misses
               continue;                                   // the fast loop waits for B and takes the byte
             }
             const uint32_t slot = (uint32_t)__builtin_ctzll(hit);
@@ -742,7 +785,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
       }
     }
     if (PROF && lane == 0 && L.debug)
-      for (int i = 0; i < 8; ++i) if (i != 5 && i != 7) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
+      for (int i = 0; i < 13; ++i) if (i != 5 && i != 7) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
     wave_sync();
   }
   if (lane == 0) S.cmd_code = kCmdExit;                  // release wave B
