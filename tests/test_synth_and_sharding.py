@@ -220,10 +220,10 @@ t = job.decode(None, None, None, decode_fn=fake)
 assert t.shape == (NB, 2) and not t[:, 0].any() and np.array_equal(t[:, 1], want_len)
 assert sorted(calls) == sorted(job.shard)
 same_everywhere(t)
-# a miss-heavy single-CM block (coded / plain ~ 1) weighs about three text-like ones of its size (zpaqhip_block_costs)
+# a miss-heavy single-CM block (coded / plain ~ 1) weighs about two text-like ones of its size (zpaqhip_block_costs)
 l1 = [b for b in range(NB) if (b % PER) % 4 == 0]
 per_byte = costs[l1] / want_len[l1]
-assert per_byte.min() < 1300 and per_byte.max() > 3000, (per_byte.min(), per_byte.max())
+assert per_byte.min() < 1300 and per_byte.max() > 2000, (per_byte.min(), per_byte.max())
 # ---- run-time queue, chunks of 256 (one block per CU): drained, every block decoded by exactly one rank
 for pass_ in range(2):
     calls.clear()

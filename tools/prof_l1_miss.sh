@@ -12,11 +12,11 @@ d = json.loads(open('/tmp/pl1.json').read().strip().splitlines()[-1])
 c = [int(x) for x in [l for l in open('/tmp/pl1.err') if l.startswith('ZPAQHIP_PROF cycles:')][-1].split(':')[1].split()]
 nbytes = 256 * 1048576
 miss = max(1, c[9])
-print(f"plaintext {k}: {d['value']:.1f} MB/s (diagnostic build), bit_exact {d['bit_exact']}; misses {c[9]} = {100.0 * c[9] / nbytes:.1f} % of bytes; "
-      f"cycles per byte in the fast loop {c[2] / nbytes:.0f}; spin waits {c[12]} ({c[12] / nbytes:.2f} per byte), {c[11] / max(1, c[12]):.0f} cycles each")
-print(f"  per miss, wave A: loop left -> miss published {c[8] / miss:.0f}; published -> back in the loop {c[10] / miss:.0f}; "
-      f"(spin while B works: see above); wave B: message seen -> requests out {c[13] / miss:.0f}; requests -> window data back {c[14] / miss:.0f}; "
-      f"data -> installed and reported {c[15] / miss:.0f}")
+print(f"plaintext {k}: {d['value']:.1f} MB/s (diagnostic build), bit_exact {d['bit_exact']}; swaps {c[9]} = {100.0 * c[9] / nbytes:.1f} % of bytes "
+      f"({c[10]} of them asked for by the C++ body); cycles per byte in the fast loop {c[2] / nbytes:.0f}; waits for wave B in the fast loop "
+      f"{c[12]} ({c[12] / nbytes:.2f} per byte), {c[11] / max(1, c[12]):.0f} cycles each")
+print(f"  per swap, wave C: request seen -> loads and write-back issued {c[13] / miss:.0f}; -> window data back {c[14] / miss:.0f}; "
+      f"-> installed and reported {c[15] / miss:.0f}   (wave A, when the C++ body asks: loop left -> request published {c[8] / max(1, c[10]):.0f})")
 PY
 done
 cat "$OUT"

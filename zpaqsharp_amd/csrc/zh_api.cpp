@@ -1188,12 +1188,12 @@ int zpaqhip_block_costs(const uint8_t *in, size_t in_len, const zpaqhip_block *b
     uint64_t w = it->second;
     if (w >= kCm1Marker - 1) {
       const uint64_t pp = w == kCm1Marker ? 0u : 1500u;
-      // zh_cm.hip: the byte loop costs the same on any data, a window miss ~3 000 cycles, and the miss rate of an order-1
-      // context follows the data's entropy — which the block shows as coded / plain.  Measured at 256 blocks per GPU
-      // (profiles/r03, r04): text 0.45 -> 1 100 cycles per byte, x86-like 0.75 -> 1 760, random 1.03 -> 3 400;
-      // piecewise linear between them (a block without a size hint counts as text)
+      // zh_cm.hip: the byte loop costs the same on any data, a window miss ~1 400 cycles more, and the miss rate of an
+      // order-1 context follows the data's entropy — which the block shows as coded / plain.  Measured at 256 blocks per GPU
+      // (profiles/r04): text 0.45 -> 1 080 cycles per byte, x86-like 0.75 -> 1 410, random 1.03 -> 2 200; piecewise linear
+      // between them (a block without a size hint counts as text)
       const double rho = hinted && plain ? (double)coded / (double)plain : 0.45;
-      w = pp + (rho <= 0.45 ? 1100u : rho <= 0.75 ? 1100u + (uint64_t)((rho - 0.45) * 2200.0) : 1760u + (uint64_t)((std::min(rho, 1.1) - 0.75) * 5900.0));
+      w = pp + (rho <= 0.45 ? 1100u : rho <= 0.75 ? 1100u + (uint64_t)((rho - 0.45) * 1030.0) : 1410u + (uint64_t)((std::min(rho, 1.1) - 0.75) * 2820.0));
     }
     cost[b] = std::max<uint64_t>(1, plain) * w;
   }

@@ -47,7 +47,7 @@ namespace {
 
 constexpr uint32_t kNoWin = 0xFFFFFFFFu;
 constexpr uint32_t kRing = 16;            // A -> B message ring (entries)
-enum : uint32_t { kMsgByte = 0, kMsgMiss = 1, kMsgLeave = 2, kMsgMissAux = 3 };   // Miss: window id in bits 6-22; MissAux: window ids in aux[]
+enum : uint32_t { kMsgByte = 0, kMsgLeave = 2 };
 enum : uint32_t { kCmdEnter = 1, kCmdExit = 3 };
 constexpr uint32_t kSpinSection = 1u << 27;   // bounded waits: nothing may hang the GPU
 constexpr uint64_t kSpinIdle = 1ull << 33;
@@ -74,8 +74,12 @@ struct alignas(64) CmBlkT {
   uint32_t dummy[64];                     // where the lanes of wave A other than lane 0 put their copy of a message (no exec switch)
   uint32_t aux[kRing][2];                 // MISS: new window, victim window
   uint32_t tags[64];                      // ENTER: slot s was trained by wave A alone since B last saw it (its p16 is stale)
-  uint32_t wtag[64];                      // ENTER: window held by slot s (wave B keeps its own copy of the directory from here on)
   uint4 wsink[64];                        // where lanes that hold no part of a window put their LDS write during a swap (no exec switch)
+  // wave A -> swap wave (wave C): mold = the victim's window (kNoWin: the slot was empty), then mreq = n(8) << 23 | window(16) << 6
+  // | slot(6) (bit 22: the window id is in aux[0][0]); wave C -> wave A: mdone = n of the last swap installed.  mcfg counts the
+  // sections (C re-reads the table's place when it changes); ~0 = leave the kernel
+  alignas(8) uint32_t mreq;               // (8-byte aligned: wave C reads {mreq, mold} as one word pair; zh_cm_fast.h addresses mold / mdone as mreq + 4 / + 8)
+  uint32_t mold, mdone, mcfg;
   uint32_t t0, b_seq;                     // message count at section start / messages completed by B
   uint32_t cmd_seq, cmd_code, cmd_ack;    // A -> B commands outside a section
   uint32_t limit, ob_word, ob_room;
@@ -91,6 +95,7 @@ struct alignas(64) CmLdsT {
   CmBlkT<NW> B[NP];
 };
 static_assert(sizeof(CmLdsT<64, 1>) <= 163840 && sizeof(CmLdsT<32, 2>) <= 163840, "LDS budget");
+static_assert(offsetof(CmBlkT<64>, mold) == offsetof(CmBlkT<64>, mreq) + 4 && offsetof(CmBlkT<64>, mdone) == offsetof(CmBlkT<64>, mreq) + 8 && offsetof(CmBlkT<64>, mreq) % 8 == 0, "swap mailbox layout");
 
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -167,14 +172,19 @@ __device__ __forceinline__ void p16_rebuild(const CmTabs &T, BLK &S, uint32_t sl
   if (lane < 16) S.p16A[slot][lane] = (uint16_t)p16_of(T, S.winA[slot][lane]);
 }
 // Replacement (round 4): the first slot whose last use is older than message `thr` — empty slots carry 0, lanes that stand
-// for no slot ~0 and are never taken; when no slot is that old the threshold moves up to 31 messages ago (at least one of
-// 32 slots was not used in 31 messages).  A handful of instructions where true LRU needed a wave-wide maximum; on the
+// for no slot ~0 and are never taken; when no slot is that old the threshold moves up to 31 (24 with 32 slots) messages ago.  A handful of instructions where true LRU needed a wave-wide maximum; on the
 // x86-like generator it misses as rarely as LRU (20.7 % against 20.5 %; first-in-first-out: 27 %).  zh_cm_fast.h does the
 // same test inline and leaves to the C++ body only when the threshold has to move.
+template <uint32_t NW> constexpr uint32_t kVictimBack = NW >= 40 ? 31u : NW - 8u;
+template <uint32_t NW>
 __device__ __forceinline__ uint32_t pick_victim(uint32_t lastuse, uint32_t now, uint32_t &thr) {
+  // every byte stamps one slot with its own message number, so at most kBack slots (and one being swapped in) carry a stamp
+  // of the last kBack messages: with kBack < NW - 1 a victim exists; kBack > 13 keeps it clear of what wave B may still owe
+  constexpr uint32_t kBack = kVictimBack<NW>;
+  static_assert(kBack > 13 && kBack + 1 < NW, "replacement threshold");
   uint64_t old = __ballot(lastuse < thr);
-  if (UNLIKELY(old == 0)) { thr = now > 31u ? now - 31u : 1u; old = __ballot(lastuse < thr); }
-  return (uint32_t)__builtin_ctzll(old);
+  if (UNLIKELY(old == 0)) { thr = now > kBack ? now - kBack : 1u; old = __ballot(lastuse < thr); }
+  return (uint32_t)__builtin_ctzll(old | 1ull << 63);      // (never empty; the guard keeps a lost invariant from indexing past the slots)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -184,7 +194,6 @@ template <bool PROF, class BLK>
 __device__ void helper_wave(const ZhLaunch &L, const CmTabs &T, BLK &S, uint32_t lane) {
   constexpr uint32_t kWin = BLK::kNW;
   uint64_t busy = 0, tb0 = 0, tb1 = 0, idle = 0;
-  uint64_t mis_a = 0, mis_b = 0, mis_c = 0;             // PROF, per miss: message seen -> requests out; -> window data back; -> installed and reported
   const uint32_t l15 = lane & 15;
   const uint32_t ltt = 31 - __clz((int)(l15 | 1));
   const uint32_t lsh_vis = 4 - ltt, lsh_y = 3 - ltt;
@@ -205,20 +214,6 @@ __device__ void helper_wave(const ZhLaunch &L, const CmTabs &T, BLK &S, uint32_t
     // ---- ENTER: take over the window cache and the output
     uint32_t *table = reinterpret_cast<uint32_t *>(L.arena + uni64(S.table));   // offsets, so that accesses stay global_*
     const uint32_t limit = uni(S.limit);
-    // window swaps (round 4): buffer accesses with one offset per lane and the window's place as the scalar offset — lanes
-    // that hold no part of a window carry an offset beyond the table and are dropped, their LDS writes go to a sink: no
-    // exec-mask code, no 64-bit address arithmetic (the round-3 form spent ~680 cycles getting its requests out and ~430
-    // installing the data, against ~130 for the data to arrive: profiles/r04/stages_l1_miss.txt)
-    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(table, 0, (int)uni(S.table_bytes), 0x00020000);
-    uint32_t tagB = S.wtag[lane];                            // this wave's copy of the directory: lane s = window in slot s
-    constexpr uint32_t kDrop = 0x80000000u;
-    const uint32_t g_offB = (64u + lane) * 16u, g_offA = lane < 4 ? lane * 16u : kDrop,
-                   g_offP = lane < 32 ? (8u + lane) * 16u : lane < 34 ? (4u + lane - 32u) * 16u : kDrop;
-    const uint32_t l_sink = lds_off(&S.wsink[lane]);
-    const uint32_t l_cB = lds_off(&S.winB[0][0]) + lane * 16u;
-    const uint32_t l_cA = lane < 4 ? lds_off(&S.winA[0][0]) + lane * 16u : l_sink, l_mA = lane < 4 ? 64u : 0u;
-    const uint32_t l_cP = lane < 32 ? lds_off(&S.p16B[0][0]) + lane * 16u : lane < 34 ? lds_off(&S.p16A[0][0]) + (lane - 32u) * 16u : l_sink,
-                   l_mP = lane < 32 ? 512u : lane < 34 ? 32u : 0u;
     OutBuf ob;
     ob.base = L.out + uni64(S.ob_base); ob.cap = uni64(S.ob_cap); ob.len = uni64(S.ob_len);
     ob.stored = uni64(S.ob_stored); ob.word = uni(S.ob_word); ob.room = uni(S.ob_room); ob.park = 0;
@@ -283,52 +278,13 @@ __device__ void helper_wave(const ZhLaunch &L, const CmTabs &T, BLK &S, uint32_t
       } else if (!have) {
         if (PROF) ++idle;
         if (++sp > kSpinSection) return;
-      } else if (type == kMsgMiss || type == kMsgMissAux) {
-        sp = 0;
-        uint64_t tm0 = 0, tm1 = 0, tm2 = 0;
-        if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm0)::"memory"); }
-        uint32_t neww, oldw;
-        if (LIKELY(type == kMsgMiss)) { neww = (m0 >> 6) & 0x1FFFFu; oldw = rdlane(tagB, slot); }
-        else { neww = uni(S.aux[u & (kRing - 1)][0]); oldw = uni(S.aux[u & (kRing - 1)][1]); }
-        tagB = lane == slot ? neww : tagB;
-        typedef __attribute__((address_space(3))) uint4 *lds_u4_p;
-        const uint32_t aB = l_cB + slot * 1024u, aA = l_cA + slot * l_mA, aP = l_cP + slot * l_mP;
-        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) v4u *lds_v4_p;
-        // request the new window first (its probability cache travels with it: win_store), write the victim back while it travels
-        const uint32_t so_new = neww * 2048u;
-        const v4u nb = __builtin_amdgcn_raw_buffer_load_b128(trs, g_offB, so_new, 0);
-        const v4u na = __builtin_amdgcn_raw_buffer_load_b128(trs, g_offA, so_new, 0);
-        const v4u np = __builtin_amdgcn_raw_buffer_load_b128(trs, g_offP, so_new, 0);
-        if (oldw != kNoWin) {
-          const v4u vb = *(lds_v4_p)aB, va = *(lds_v4_p)aA, vp = *(lds_v4_p)aP;
-          const uint32_t so_old = oldw * 2048u;
-          __builtin_amdgcn_raw_buffer_store_b128(vb, trs, g_offB, so_old, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(va, trs, g_offA, so_old, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(vp, trs, g_offP, so_old, 0);
-        }
-        if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm1)::"memory"); asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // the window's three loads are back (the victim's stores need not be)
-                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm2)::"memory"); mis_a += tm1 - tm0; mis_b += tm2 - tm1; }
-        *(lds_v4_p)aB = nb;
-        *(lds_v4_p)aA = na;
-        *(lds_v4_p)aP = np;
-        ++u;
-        // LDS data, then LDS flag, in program order (lds_order): no fence — a release fence here would also wait for the
-        // victim's write-back, a full store round trip that wave A has no reason to sit through (only this wave ever
-        // reads that window back, and its own memory operations stay in order)
-        lds_order();
-        lds_put0(&S.b_seq, u);
-        if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm0)::"memory"); mis_c += tm0 - tm2; }
       } else {                                             // LEAVE: hand the output state back
         out_flush(ob, lane);
         if (PROF && lane == 0 && L.debug) {
           atomicAdd((unsigned long long *)&L.debug[5], (unsigned long long)busy);
           atomicAdd((unsigned long long *)&L.debug[7], (unsigned long long)idle);
-          atomicAdd((unsigned long long *)&L.debug[13], (unsigned long long)mis_a);
-          atomicAdd((unsigned long long *)&L.debug[14], (unsigned long long)mis_b);
-          atomicAdd((unsigned long long *)&L.debug[15], (unsigned long long)mis_c);
         }
-        busy = 0; idle = 0; mis_a = mis_b = mis_c = 0;
+        busy = 0; idle = 0;
         if (lane == 0) { S.ob_len = ob.len; S.ob_stored = ob.stored; S.ob_word = ob.word; S.ob_room = ob.room; }
         ++u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -339,29 +295,118 @@ __device__ void helper_wave(const ZhLaunch &L, const CmTabs &T, BLK &S, uint32_t
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Wave C: window swaps (round 4).  A miss used to travel through wave B's message ring, behind the byte before it, and
+// wave A then waited for B to train that byte AND swap the window: ~3 000 cycles, of which the memory round trip was ~130
+// (profiles/r04/stages_l1_miss_before.txt).  Nothing in a swap depends on B: the victim is a slot nobody has used for more
+// than 31 messages (B is never more than 13 behind), the new window arrives with its probability cache (win_store).  So a
+// third wavefront does nothing but swaps: wave A hands it slot, window and victim through three LDS words and goes on as
+// soon as the window is installed, while B is still training the byte before.
+// Buffer accesses with one offset per lane and the window's place as the scalar offset — lanes that hold no part of a
+// window carry an offset beyond the table and are dropped, their LDS writes go to a sink: no exec-mask code, no 64-bit
+// address arithmetic.  Stateless between requests (the directory stays with wave A).
+// ---------------------------------------------------------------------------------------
+template <bool PROF, class BLK>
+__device__ void swap_wave(const ZhLaunch &L, BLK &S, uint32_t lane) {
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) v4u *lds_v4_p;
+  constexpr uint32_t kDrop = 0x80000000u;
+  const uint32_t g_offB = (64u + lane) * 16u, g_offA = lane < 4 ? lane * 16u : kDrop,
+                 g_offP = lane < 32 ? (8u + lane) * 16u : lane < 34 ? (4u + lane - 32u) * 16u : kDrop;
+  const uint32_t l_sink = lds_off(&S.wsink[lane]);
+  const uint32_t l_cB = lds_off(&S.winB[0][0]) + lane * 16u;
+  const uint32_t l_cA = lane < 4 ? lds_off(&S.winA[0][0]) + lane * 16u : l_sink, l_mA = lane < 4 ? 64u : 0u;
+  const uint32_t l_cP = lane < 32 ? lds_off(&S.p16B[0][0]) + lane * 16u : lane < 34 ? lds_off(&S.p16A[0][0]) + (lane - 32u) * 16u : l_sink,
+                 l_mP = lane < 32 ? 512u : lane < 34 ? 32u : 0u;
+  uint64_t t_req = 0, t_out = 0, t_back = 0, t_done = 0, c_a = 0, c_b = 0, c_c = 0, n_sw = 0;
+  __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void *)L.arena, 0, 0, 0x00020000);
+  uint32_t cfg = 0, done = 0;
+  uint64_t idle = 0;
+  for (;;) {
+    // {mreq, mold} in one 8-byte read (wave A writes mold first and LDS serves a wave's requests in order, so a new request
+    // word comes with its victim), the section counter beside it: one LDS round trip per poll
+    const uint64_t rq = __hip_atomic_load(reinterpret_cast<const uint64_t *>(&S.mreq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (an atomic load: a plain one would be hoisted out of the poll)
+    const uint32_t cfg_now = lds_ld(&S.mcfg);
+    const uint32_t r = uni((uint32_t)rq);
+    const uint32_t n = (r >> 23) & 255u;
+    if (n == done) {                                       // nothing to do: is the kernel over?
+      const uint32_t c = uni(cfg_now);
+      if (c == ~0u) break;
+      if (++idle > 64) __builtin_amdgcn_s_sleep(2);        // (a miss-heavy stream keeps this wave awake)
+      if (idle > kSpinIdle) break;
+      continue;
+    }
+    idle = 0;
+    if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_req)::"memory"); }
+    const uint32_t c = uni(cfg_now);
+    if (UNLIKELY(c != cfg)) {                              // a new section (or block): where its table is
+      cfg = c;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      trs = __builtin_amdgcn_make_buffer_rsrc((void *)(L.arena + uni64(S.table)), 0, (int)uni(S.table_bytes), 0x00020000);
+    }
+    const uint32_t sl = r & 63u;
+    const uint32_t neww = (r >> 22) & 1u ? uni(S.aux[0][0]) : (r >> 6) & 0xFFFFu;
+    const uint32_t oldw = uni((uint32_t)(rq >> 32));
+    const uint32_t aB = l_cB + sl * 1024u, aA = l_cA + sl * l_mA, aP = l_cP + sl * l_mP;
+    const uint32_t so_new = neww * 2048u;
+    const v4u nb = __builtin_amdgcn_raw_buffer_load_b128(trs, g_offB, so_new, 0);   // its probability cache travels with it (win_store)
+    const v4u na = __builtin_amdgcn_raw_buffer_load_b128(trs, g_offA, so_new, 0);
+    const v4u np = __builtin_amdgcn_raw_buffer_load_b128(trs, g_offP, so_new, 0);
+    if (oldw != kNoWin) {                                  // the victim goes back while the new window travels
+      const v4u vb = *(lds_v4_p)aB, va = *(lds_v4_p)aA, vp = *(lds_v4_p)aP;
+      const uint32_t so_old = oldw * 2048u;
+      __builtin_amdgcn_raw_buffer_store_b128(vb, trs, g_offB, so_old, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(va, trs, g_offA, so_old, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(vp, trs, g_offP, so_old, 0);
+    }
+    if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_out)::"memory"); asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_back)::"memory"); }
+    *(lds_v4_p)aB = nb;
+    *(lds_v4_p)aA = na;
+    *(lds_v4_p)aP = np;
+    // LDS data, then LDS flag, in program order: no fence — a release fence would also wait for the victim's write-back, a
+    // store round trip wave A has no reason to sit through (only this wave ever reads that window back, and its own memory
+    // operations stay in order)
+    lds_order();
+    lds_put0(&S.mdone, n);
+    done = n;
+    if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_done)::"memory");
+                c_a += t_out - t_req; c_b += t_back - t_out; c_c += t_done - t_back; ++n_sw; }
+  }
+  if (PROF && lane == 0 && L.debug) {
+    atomicAdd((unsigned long long *)&L.debug[13], (unsigned long long)c_a);
+    atomicAdd((unsigned long long *)&L.debug[14], (unsigned long long)c_b);
+    atomicAdd((unsigned long long *)&L.debug[15], (unsigned long long)c_c);
+    atomicAdd((unsigned long long *)&L.debug[9], (unsigned long long)n_sw);
+  }
+}
+
 template <bool PROF, uint32_t NW, uint32_t NP>
 __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP> &SS) {
   uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tprev = 0, t_exit = 0, t_pub = 0;           // PROF: stamps of the miss path (asm loop left, miss published)
   bool was_miss = false;
-  const uint32_t lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 1, pair = threadIdx.x >> 7;   // a block = one pair of wavefronts
+  // a block = three wavefronts: A (decoder), B (model, probability cache, output), C (window swaps)
+  const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, pair = NP > 1 ? wid / 3u : 0u, wave = NP > 1 ? wid - pair * 3u : wid;
   CmTabs &T = SS.T;
-  CmBlkT<NW> &S = SS.B[NP > 1 ? pair : 0];
+  CmBlkT<NW> &S = SS.B[pair];
 
   {  // model-independent tables -> LDS (both waves)
     const uint4 *s0 = reinterpret_cast<const uint4 *>(L.tables->stretch + 16384);
     uint4 *d0 = reinterpret_cast<uint4 *>(T.sh);
-    for (uint32_t i = threadIdx.x; i < sizeof(T.sh) / 16; i += 128 * NP) d0[i] = s0[i];
+    for (uint32_t i = threadIdx.x; i < sizeof(T.sh) / 16; i += 192 * NP) d0[i] = s0[i];
     const uint4 *s1 = reinterpret_cast<const uint4 *>(L.tables->squash);
     uint4 *d1 = reinterpret_cast<uint4 *>(T.sq);
-    for (uint32_t i = threadIdx.x; i < sizeof(T.sq) / 16; i += 128 * NP) d1[i] = s1[i];
+    for (uint32_t i = threadIdx.x; i < sizeof(T.sq) / 16; i += 192 * NP) d1[i] = s1[i];
     const uint4 *s2 = reinterpret_cast<const uint4 *>(L.tables->dt);
     uint4 *d2 = reinterpret_cast<uint4 *>(T.dt);
-    for (uint32_t i = threadIdx.x; i < sizeof(T.dt) / 16; i += 128 * NP) d2[i] = s2[i];
-    if ((threadIdx.x & 127) == 0) { S.cmd_seq = 0; S.cmd_code = 0; S.cmd_ack = 0; S.t0 = 0; S.b_seq = 0; }
+    for (uint32_t i = threadIdx.x; i < sizeof(T.dt) / 16; i += 192 * NP) d2[i] = s2[i];
+    if (wave == 0 && lane == 0) { S.cmd_seq = 0; S.cmd_code = 0; S.cmd_ack = 0; S.t0 = 0; S.b_seq = 0; S.mreq = 0; S.mold = 0; S.mdone = 0; S.mcfg = 0; }
   }
   __syncthreads();                                       // the only workgroup barrier of the kernel
   if (wave == 1) { helper_wave<PROF>(L, T, S, lane); return; }
+  if (wave == 2) { swap_wave<PROF>(L, S, lane); return; }
+  uint32_t n_miss = 0, sec_cfg = 0;                      // swap requests made to wave C so far / sections entered (S.mcfg)
   uint32_t cmd_seq = 0;                                  // commands issued to wave B so far
 
   // per-lane constants of the lane <-> table-entry mapping
@@ -372,7 +417,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
   // LDS offsets of what this lane reads per byte: probability of first-nibble node l15 (+ slot * 32) and the
   // four second-nibble candidates of quad lgrp (+ slot * 512)
   const uint32_t p_la = lds_off(&S.p16A[0][0]) + l15 * 2, p_lb = lds_off(&S.p16B[0][0]) + lgrp * 128 + l15 * 8;
-  const uint32_t ring_addr = lds_off(&S.ring[0]), bseq_addr = lds_off(&S.b_seq);
+  const uint32_t ring_addr = lds_off(&S.ring[0]), bseq_addr = lds_off(&S.b_seq), mreq_addr = lds_off(&S.mreq);   // (mold, mdone follow mreq)
   const uint32_t dummy_addr = lds_off(&S.dummy[lane]), ring_step = lane == 0 ? 63u : 0u;   // see ZH_FAST_EPILOGUE
 
   uint8_t *slot_mem = L.arena + (uint64_t)(blockIdx.x * NP + pair) * L.arena_stride;   // the host sizes the arena for grid x NP slots
@@ -490,7 +535,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
           uint32_t slot;
           if (LIKELY(hit != 0)) slot = (uint32_t)__builtin_ctzll(hit);
           else {                                        // swap the window in (wave A alone: nothing is in flight)
-            slot = uni(pick_victim(lastuse, t, thr));
+            slot = uni(pick_victim<NW>(lastuse, t, thr));
             const uint32_t old = rdlane(tag, slot);
             if (old != kNoWin) {
               if (rdlane(stale, slot)) { p16_rebuild(T, S, slot, lane); wave_sync(); }   // trained here, cache not refreshed yet
@@ -571,13 +616,13 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
           // ===== steady state: PASS post-processor (PostProcessor.cs:49-51), two wavefronts =====
           // hand the window cache and the output to wave B
           S.tags[lane] = stale;
-          S.wtag[lane] = tag;
           stale = 0;
           if (lane < kRing) S.ring[lane] = ((ring_tag(t) + 64) & 127) << 25;   // never the tag of messages t .. t+15
           out_flush(ob, lane);
           if (lane == 0) {
             S.table = (uint64_t)(reinterpret_cast<uint8_t *>(table) - L.arena); S.limit = limit;
             S.table_bytes = (uint32_t)(cm_bytes > 0xFFFFF000ull ? 0xFFFFF000ull : cm_bytes);
+            S.mcfg = ++sec_cfg;                           // wave C: a new section (published with the fence below, before any request)
             S.ob_base = (uint64_t)(ob.base - L.out); S.ob_cap = ob.cap; S.ob_len = ob.len; S.ob_stored = ob.stored;
             S.ob_word = ob.word; S.ob_room = ob.room;
             S.t0 = t; S.b_seq = t; S.cmd_code = kCmdEnter;
@@ -619,7 +664,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
               if (in.avail - in.k < 40 && in.avail == 256) in_seek(in, in_pos(in), lane);   // re-centre the chunk
               uint32_t code;
               d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr); in.k = uni(in.k); in.avail = uni(in.avail);
-              t = uni(t); h0 = uni(h0); b_done = uni(b_done);
+              t = uni(t); h0 = uni(h0); b_done = uni(b_done); n_miss = uni(n_miss); thr = uni(thr);
               uint64_t f0 = 0, f1 = 0;
               const uint32_t t_in = t;
               if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(f0)::"memory"); }
@@ -627,14 +672,13 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
                 const uint32_t klim = uni(in.avail >= 40 ? in.avail - 40 : 0u);
                 uint32_t vr = lane == 0 ? ring_addr + (t & (kRing - 1)) * 4u : dummy_addr;
                 if (PROF) {
-                  if (was_miss) { prof[10] += f0 - t_pub; was_miss = false; }     // miss published -> back in the loop
                   uint32_t sp_lo = 0, sp_hi = 0, nsp = 0;
                   ZH_CM_FAST_LOOP_PROF(d.low, d.high, d.curr, in.k, t, h0, b_done, lastuse, code, klim, uni(win_bfe), uni(hshift),
-                                       vr, ring_step, bseq_addr, in.cur, tag, p_la, p_lb, uni(thr), sp_lo, sp_hi, nsp);
+                                       vr, ring_step, bseq_addr, in.cur, tag, p_la, p_lb, thr, n_miss, mreq_addr, uni(kVictimBack<NW>), sp_lo, sp_hi, nsp);
                   prof[11] += (uint64_t)sp_hi << 32 | sp_lo; prof[12] += nsp;     // cycles / times wave A waited in the spin
                 } else {
                 ZH_CM_FAST_LOOP(d.low, d.high, d.curr, in.k, t, h0, b_done, lastuse, code, klim, uni(win_bfe), uni(hshift),
-                                vr, ring_step, bseq_addr, in.cur, tag, p_la, p_lb, uni(thr));
+                                vr, ring_step, bseq_addr, in.cur, tag, p_la, p_lb, thr, n_miss, mreq_addr, uni(kVictimBack<NW>));
                 }
               } else code = 0;
               if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(f1)::"memory"); prof[2] += f1 - f0; prof[3] += t - t_in; t_exit = f1; }
@@ -653,22 +697,31 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
             // ---- the byte's window (before any coder state changes, so that a miss can simply start over)
             const uint32_t w = (h0 & cm_mask) >> 9;
             const uint64_t hit = __ballot(tag == w);
-            if (UNLIKELY(hit == 0)) {                     // window miss: wave B swaps the window in (the fast loop serves a miss itself
-              thr = uni(thr);                             // unless the replacement threshold has to move or the id is too wide for a message)
-              const uint32_t vs = uni(pick_victim(lastuse, t, thr));
+            if (UNLIKELY(hit == 0)) {                     // window miss: wave C swaps the window in (the fast loop asks for that itself
+              thr = uni(thr);                             // unless the replacement threshold has to move or the id is too wide for the request word)
+              const uint32_t vs = uni(pick_victim<NW>(lastuse, t, thr));
               const uint32_t old = rdlane(tag, vs);
               tag = lane == vs ? w : tag;
-              if (w < 0x20000u) publish(kMsgMiss << 23 | w << 6 | vs);
-              else {
-                if (lane == 0) { uint32_t *q = S.aux[t & (kRing - 1)]; q[0] = w; q[1] = old; }
-                publish(kMsgMissAux << 23 | vs);
-              }
-              lastuse = lane == vs ? t : lastuse;
-              if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_pub)::"memory"); prof[8] += t_pub - t_exit; prof[9] += 1; was_miss = true; }   // loop left -> miss published; misses
-              continue;                                   // the fast loop waits for B and takes the byte
+              n_miss = uni(n_miss + 1);
+              const uint32_t nn = n_miss & 255u;
+              if (w >= 0x10000u && lane == 0) S.aux[0][0] = w;
+              lds_st(&S.mold, old);
+              lds_order();
+              lds_put0(&S.mreq, nn << 23 | (w >= 0x10000u ? 1u << 22 : w << 6) | vs);
+              // a window fresh from the table has nothing outstanding with wave B: stamped as if used 13 messages ago (the ring's depth)
+              lastuse = lane == vs ? (t > 13u ? t - 13u : 1u) : lastuse;
+              if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_pub)::"memory"); prof[8] += t_pub - t_exit; prof[10] += 1; }   // loop left -> request published
+              { uint32_t spn = 0; while (uni(lds_ld(&S.mdone)) != nn) { if (++spn > kSpinSection) { ev = kEvHelper; d.low = d.high = d.curr = 1; break; } } }
+              lds_order();
+              continue;                                   // the fast loop takes the byte
             }
             const uint32_t slot = (uint32_t)__builtin_ctzll(hit);
             uint32_t bad = 0, err = 0, helper_lost = 0;
+            {  // a swap the fast loop asked for and gave up waiting on (it never does in practice) must be in before the window is read
+              uint32_t spn = 0;
+              while (UNLIKELY(uni(lds_ld(&S.mdone)) != (n_miss & 255u))) { if (++spn > kSpinSection) { helper_lost = 1; break; } }
+              lds_order();
+            }
             d.low += 1;
             if (UNLIKELY((d.high ^ d.low) < 0x1000000u)) {
               if (dec_renorm_chk(d, in, lane, bad)) err = kEvEof;
@@ -788,42 +841,42 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
       for (int i = 0; i < 13; ++i) if (i != 5 && i != 7) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
     wave_sync();
   }
-  if (lane == 0) S.cmd_code = kCmdExit;                  // release wave B
+  if (lane == 0) { S.cmd_code = kCmdExit; S.mcfg = ~0u; }   // release waves B and C
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   lds_st(&S.cmd_seq, cmd_seq + 1);
 }
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(128) void zh_decode_cm(ZhLaunch L) {
+extern "C" __global__ __launch_bounds__(192) void zh_decode_cm(ZhLaunch L) {
   __shared__ CmLdsT<64, 1> S;
   decode_cm_body<false, 64, 1>(L, S);
 }
 
 // Two blocks per workgroup (four wavefronts, 32 windows per block): taken by the host when a launch has more blocks than
 // the GPU has CUs (zh_api.cpp), so that an archive of many blocks uses all four SIMDs of every CU.
-extern "C" __global__ __launch_bounds__(256) void zh_decode_cm_x2(ZhLaunch L) {
+extern "C" __global__ __launch_bounds__(384) void zh_decode_cm_x2(ZhLaunch L) {
   __shared__ CmLdsT<32, 2> S;
   decode_cm_body<false, 32, 2>(L, S);
 }
 
-extern "C" __global__ __launch_bounds__(128) void zh_decode_cm_prof(ZhLaunch L) {
+extern "C" __global__ __launch_bounds__(192) void zh_decode_cm_prof(ZhLaunch L) {
   __shared__ CmLdsT<64, 1> S;
   decode_cm_body<true, 64, 1>(L, S);
 }
 
 extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL(zh_decode_cm_prof, dim3(grid), dim3(128), 0, stream, *L);
+  hipLaunchKernelGGL(zh_decode_cm_prof, dim3(grid), dim3(192), 0, stream, *L);
   return hipGetLastError();
 }
 
 extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL(zh_decode_cm, dim3(grid), dim3(128), 0, stream, *L);
+  hipLaunchKernelGGL(zh_decode_cm, dim3(grid), dim3(192), 0, stream, *L);
   return hipGetLastError();
 }
 
 // grid workgroups of two blocks each: the arena must hold 2 x grid slots
 extern "C" hipError_t zh_launch_cm_x2(const ZhLaunch *L, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL(zh_decode_cm_x2, dim3(grid), dim3(256), 0, stream, *L);
+  hipLaunchKernelGGL(zh_decode_cm_x2, dim3(grid), dim3(384), 0, stream, *L);
   return hipGetLastError();
 }

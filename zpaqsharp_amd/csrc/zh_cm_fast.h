@@ -214,7 +214,7 @@
   ZH_FAST_EPILOGUE                                                    \
   "s_branch .Lzh_slow_%=\n"
 
-#define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_, thr_) \
+#define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_, thr_, nm_, mqa_, kb_) \
   asm volatile(                                                       \
   "v_mov_b32_e32 v249, 0\n\t"                                         \
   "s_branch .Lzh_byte_%=\n\t"   /* over the alignment padding: up to 63 s_nop, ~150 cycles per entry on average, and a window miss enters anew */ \
@@ -226,34 +226,54 @@
   /* ---- out of line ---- */                                         \
   ZH_CM_FAST_COLD(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, "", "")               \
   ZH_CM_FAST_COLD(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, "", "")      \
-  /* ---- window miss, served without leaving the loop (round 4: the stage table of a miss, profiles/r04/stages_l1_miss.txt, \
-     showed ~1 000 of its ~3 000 cycles between leaving this loop and re-entering it).  Victim = the first slot not used \
-     since message `thr` (empty slots carry 0, lanes that stand for no slot ~0); the directory is updated here, wave B gets \
-     slot and window in ONE message (it keeps its own copy of the directory for the victim's id) and the byte starts over: \
-     the lookup then hits and the lag test (0 messages since the slot's last use) holds the wave in the spin until B has \
-     installed the window.  No candidate, or a window id beyond 17 bits: the C++ body serves it. */ \
+  /* ---- window miss, served without leaving the loop (round 4: the stage table of a miss, profiles/r04/stages_l1_miss_before.txt, \
+     showed ~1 000 of its ~3 000 cycles between leaving this loop and re-entering it, and most of the rest waiting for wave B to \
+     finish the byte before).  Victim = the first slot not used since message `thr` (empty slots carry 0, lanes that stand for no \
+     slot ~0); the directory is updated here and the swap wave (wave C, zh_cm.hip) gets victim, window and slot through three LDS \
+     words — every lane writes the same value to the same word: no exec switch —; the wave spins on C's answer and starts the \
+     byte over: the lookup then hits.  The fresh window is stamped as if used 13 messages ago: nothing of it is outstanding with \
+     wave B, 13 is what the ring can hold.  No candidate, or a window id beyond 16 bits: the C++ body serves it. */ \
   ".Lzh_miss_%=:\n\t"                                                 \
-  "s_cmp_ge_u32 s81, 0x20000\n\t"                                     \
+  "s_cmp_ge_u32 s81, 0x10000\n\t"                                     \
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
   "v_cmp_gt_u32_e32 vcc, %[thr], %[lu]\n\t"                           \
-  "s_cbranch_vccz .Lzh_slow_%=\n\t"                                   \
+  "s_cbranch_vccnz .Lzh_mvic_%=\n\t"                                  \
+  /* no slot that old: the threshold moves up to kb messages ago (pick_victim in zh_cm.hip is the same rule) */ \
+  "s_sub_u32 %[thr], %[t], %[kb]\n\t"                                 \
+  "s_max_i32 %[thr], %[thr], 1\n\t"                                   \
+  "v_cmp_gt_u32_e32 vcc, %[thr], %[lu]\n\t"                           \
+  "s_cbranch_vccz .Lzh_slow_%=\n"                                     \
+  ".Lzh_mvic_%=:\n\t"                                                 \
   "s_ff1_i32_b64 s82, vcc\n\t"                                        \
   "s_mov_b32 s84, m0\n\t"                                             \
   "s_mov_b32 m0, s82\n\t"                                             \
-  "s_lshl_b32 s80, %[t], 25\n\t"                                      \
-  "s_lshl_b32 s85, s81, 6\n\t"                                        \
-  "s_or_b32 s80, s80, s85\n\t"                                        \
+  "s_add_u32 %[nm], %[nm], 1\n\t"                                     \
+  "s_and_b32 s85, %[nm], 0xff\n\t"                                    \
+  "s_lshl_b32 s80, s85, 23\n\t"                                       \
+  "s_lshl_b32 s86, s81, 6\n\t"                                        \
+  "s_or_b32 s80, s80, s86\n\t"                                        \
   "s_or_b32 s80, s80, s82\n\t"                                        \
-  "s_or_b32 s80, s80, 0x800000\n\t"                                   \
+  "v_readlane_b32 s83, %[tag], m0\n\t"                                \
   "v_writelane_b32 %[tag], s81, m0\n\t"                               \
+  "v_mov_b32_e32 v250, s83\n\t"                                       \
+  "ds_write_b32 %[mqa], v250 offset:4\n\t"                            \
   "v_mov_b32_e32 v250, s80\n\t"                                       \
-  "ds_write_b32 %[vr], v250\n\t"                                      \
-  "v_add_u32_e32 v252, 4, %[vr]\n\t"                                  \
-  "v_bfi_b32 %[vr], %[vm], v252, %[vr]\n\t"                           \
-  "s_add_u32 %[t], %[t], 1\n\t"                                       \
-  "v_writelane_b32 %[lu], %[t], m0\n\t"                               \
+  "ds_write_b32 %[mqa], v250\n\t"                                     \
+  "s_sub_u32 s87, %[t], 13\n\t"                                       \
+  "s_max_i32 s87, s87, 1\n\t"                                         \
+  "v_writelane_b32 %[lu], s87, m0\n\t"                                \
   "s_mov_b32 m0, s84\n\t"                                             \
-  "s_branch .Lzh_byte_%=\n"                                           \
+  "s_mov_b32 s80, 0x4000\n"                                           \
+  ".Lzh_mspin_%=:\n\t"                                                \
+  "ds_read_b32 v252, %[mqa] offset:8\n\t"                             \
+  "s_waitcnt lgkmcnt(0)\n\t"                                          \
+  "v_readfirstlane_b32 s86, v252\n\t"                                 \
+  "s_cmp_eq_u32 s86, s85\n\t"                                         \
+  "s_cbranch_scc1 .Lzh_byte_%=\n\t"                                   \
+  "s_sub_u32 s80, s80, 1\n\t"                                         \
+  "s_cmp_lg_u32 s80, 0\n\t"                                           \
+  "s_cbranch_scc1 .Lzh_mspin_%=\n\t"                                  \
+  "s_branch .Lzh_slow_%=\n"                                           \
   ".Lzh_corrupt_%=:\n\t"                                              \
   "s_mov_b32 %[code], 1\n\t"                                          \
   "s_branch .Lzh_end_%=\n"                                            \
@@ -262,16 +282,16 @@
   "s_mov_b32 %[code], 0\n"                                            \
   ".Lzh_end_%=:\n\t"                                                  \
   : [low] "+s"(low_), [high] "+s"(high_), [curr] "+s"(curr_), [k] "+s"(k_), [t] "+s"(t_), [h0] "+s"(h0_), \
-    [bdone] "+s"(bdone_), [lu] "+v"(lu_), [vr] "+v"(vr_), [tag] "+v"(tag_), [code] "=s"(code_)          \
+    [bdone] "+s"(bdone_), [lu] "+v"(lu_), [vr] "+v"(vr_), [tag] "+v"(tag_), [nm] "+s"(nm_), [thr] "+s"(thr_), [code] "=s"(code_)          \
   : [klim] "s"(klim_), [bfe] "s"(bfe_), [hs] "s"(hs_), [vm] "v"(vm_), [bsa] "v"(bsa_),             \
-    [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [thr] "s"(thr_)                        \
+    [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [mqa] "v"(mqa_), [kb] "s"(kb_)                        \
   : "memory", "scc", "vcc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",   \
     "s91", "s92", "s94", "v249", "v250", "v251", "v252")
 // Diagnostic build (zh_decode_cm_prof): the same loop with the cycles spent in the spin (wave A waiting for wave B: a window
 // being swapped in, or B behind by more than the window's lag allowance) summed into spin_ (s96-s101 are scratch here).
 #define ZH_FAST_SPIN_IN "s_memtime s[96:97]\n\t"
 #define ZH_FAST_SPIN_OK "s_memtime s[98:99]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s98, s98, s96\n\ts_subb_u32 s99, s99, s97\n\ts_add_u32 s100, s100, s98\n\ts_addc_u32 s101, s101, s99\n\ts_add_u32 %[nspin], %[nspin], 1\n\t"
-#define ZH_CM_FAST_LOOP_PROF(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_, thr_, spin_lo_, spin_hi_, nspin_) \
+#define ZH_CM_FAST_LOOP_PROF(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_, thr_, nm_, mqa_, kb_, spin_lo_, spin_hi_, nspin_) \
   asm volatile(                                                       \
   "v_mov_b32_e32 v249, 0\n\t"                                         \
   "s_mov_b32 s100, 0\n\t"                                             \
@@ -284,34 +304,54 @@
   "s_branch .Lzh_byte_%=\n"                                           \
   ZH_CM_FAST_COLD(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, ZH_FAST_SPIN_IN, ZH_FAST_SPIN_OK)              \
   ZH_CM_FAST_COLD(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, ZH_FAST_SPIN_IN, ZH_FAST_SPIN_OK)     \
-  /* ---- window miss, served without leaving the loop (round 4: the stage table of a miss, profiles/r04/stages_l1_miss.txt, \
-     showed ~1 000 of its ~3 000 cycles between leaving this loop and re-entering it).  Victim = the first slot not used \
-     since message `thr` (empty slots carry 0, lanes that stand for no slot ~0); the directory is updated here, wave B gets \
-     slot and window in ONE message (it keeps its own copy of the directory for the victim's id) and the byte starts over: \
-     the lookup then hits and the lag test (0 messages since the slot's last use) holds the wave in the spin until B has \
-     installed the window.  No candidate, or a window id beyond 17 bits: the C++ body serves it. */ \
+  /* ---- window miss, served without leaving the loop (round 4: the stage table of a miss, profiles/r04/stages_l1_miss_before.txt, \
+     showed ~1 000 of its ~3 000 cycles between leaving this loop and re-entering it, and most of the rest waiting for wave B to \
+     finish the byte before).  Victim = the first slot not used since message `thr` (empty slots carry 0, lanes that stand for no \
+     slot ~0); the directory is updated here and the swap wave (wave C, zh_cm.hip) gets victim, window and slot through three LDS \
+     words — every lane writes the same value to the same word: no exec switch —; the wave spins on C's answer and starts the \
+     byte over: the lookup then hits.  The fresh window is stamped as if used 13 messages ago: nothing of it is outstanding with \
+     wave B, 13 is what the ring can hold.  No candidate, or a window id beyond 16 bits: the C++ body serves it. */ \
   ".Lzh_miss_%=:\n\t"                                                 \
-  "s_cmp_ge_u32 s81, 0x20000\n\t"                                     \
+  "s_cmp_ge_u32 s81, 0x10000\n\t"                                     \
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
   "v_cmp_gt_u32_e32 vcc, %[thr], %[lu]\n\t"                           \
-  "s_cbranch_vccz .Lzh_slow_%=\n\t"                                   \
+  "s_cbranch_vccnz .Lzh_mvic_%=\n\t"                                  \
+  /* no slot that old: the threshold moves up to kb messages ago (pick_victim in zh_cm.hip is the same rule) */ \
+  "s_sub_u32 %[thr], %[t], %[kb]\n\t"                                 \
+  "s_max_i32 %[thr], %[thr], 1\n\t"                                   \
+  "v_cmp_gt_u32_e32 vcc, %[thr], %[lu]\n\t"                           \
+  "s_cbranch_vccz .Lzh_slow_%=\n"                                     \
+  ".Lzh_mvic_%=:\n\t"                                                 \
   "s_ff1_i32_b64 s82, vcc\n\t"                                        \
   "s_mov_b32 s84, m0\n\t"                                             \
   "s_mov_b32 m0, s82\n\t"                                             \
-  "s_lshl_b32 s80, %[t], 25\n\t"                                      \
-  "s_lshl_b32 s85, s81, 6\n\t"                                        \
-  "s_or_b32 s80, s80, s85\n\t"                                        \
+  "s_add_u32 %[nm], %[nm], 1\n\t"                                     \
+  "s_and_b32 s85, %[nm], 0xff\n\t"                                    \
+  "s_lshl_b32 s80, s85, 23\n\t"                                       \
+  "s_lshl_b32 s86, s81, 6\n\t"                                        \
+  "s_or_b32 s80, s80, s86\n\t"                                        \
   "s_or_b32 s80, s80, s82\n\t"                                        \
-  "s_or_b32 s80, s80, 0x800000\n\t"                                   \
+  "v_readlane_b32 s83, %[tag], m0\n\t"                                \
   "v_writelane_b32 %[tag], s81, m0\n\t"                               \
+  "v_mov_b32_e32 v250, s83\n\t"                                       \
+  "ds_write_b32 %[mqa], v250 offset:4\n\t"                            \
   "v_mov_b32_e32 v250, s80\n\t"                                       \
-  "ds_write_b32 %[vr], v250\n\t"                                      \
-  "v_add_u32_e32 v252, 4, %[vr]\n\t"                                  \
-  "v_bfi_b32 %[vr], %[vm], v252, %[vr]\n\t"                           \
-  "s_add_u32 %[t], %[t], 1\n\t"                                       \
-  "v_writelane_b32 %[lu], %[t], m0\n\t"                               \
+  "ds_write_b32 %[mqa], v250\n\t"                                     \
+  "s_sub_u32 s87, %[t], 13\n\t"                                       \
+  "s_max_i32 s87, s87, 1\n\t"                                         \
+  "v_writelane_b32 %[lu], s87, m0\n\t"                                \
   "s_mov_b32 m0, s84\n\t"                                             \
-  "s_branch .Lzh_byte_%=\n"                                           \
+  "s_mov_b32 s80, 0x4000\n"                                           \
+  ".Lzh_mspin_%=:\n\t"                                                \
+  "ds_read_b32 v252, %[mqa] offset:8\n\t"                             \
+  "s_waitcnt lgkmcnt(0)\n\t"                                          \
+  "v_readfirstlane_b32 s86, v252\n\t"                                 \
+  "s_cmp_eq_u32 s86, s85\n\t"                                         \
+  "s_cbranch_scc1 .Lzh_byte_%=\n\t"                                   \
+  "s_sub_u32 s80, s80, 1\n\t"                                         \
+  "s_cmp_lg_u32 s80, 0\n\t"                                           \
+  "s_cbranch_scc1 .Lzh_mspin_%=\n\t"                                  \
+  "s_branch .Lzh_slow_%=\n"                                           \
   ".Lzh_corrupt_%=:\n\t"                                              \
   "s_mov_b32 %[code], 1\n\t"                                          \
   "s_branch .Lzh_end_%=\n"                                            \
@@ -322,9 +362,9 @@
   "s_mov_b32 %[splo], s100\n\t"                                       \
   "s_mov_b32 %[sphi], s101\n\t"                                       \
   : [low] "+s"(low_), [high] "+s"(high_), [curr] "+s"(curr_), [k] "+s"(k_), [t] "+s"(t_), [h0] "+s"(h0_), \
-    [bdone] "+s"(bdone_), [lu] "+v"(lu_), [vr] "+v"(vr_), [tag] "+v"(tag_), [code] "=s"(code_), [splo] "=s"(spin_lo_), [sphi] "=s"(spin_hi_), [nspin] "+s"(nspin_) \
+    [bdone] "+s"(bdone_), [lu] "+v"(lu_), [vr] "+v"(vr_), [tag] "+v"(tag_), [nm] "+s"(nm_), [thr] "+s"(thr_), [code] "=s"(code_), [splo] "=s"(spin_lo_), [sphi] "=s"(spin_hi_), [nspin] "+s"(nspin_) \
   : [klim] "s"(klim_), [bfe] "s"(bfe_), [hs] "s"(hs_), [vm] "v"(vm_), [bsa] "v"(bsa_),             \
-    [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [thr] "s"(thr_)                        \
+    [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [mqa] "v"(mqa_), [kb] "s"(kb_)                        \
   : "memory", "scc", "vcc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",   \
     "s91", "s92", "s94", "s96", "s97", "s98", "s99", "s100", "s101", "v249", "v250", "v251", "v252")
 // clang-format on
