@@ -37,7 +37,8 @@ using namespace zhdev;
 
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 
-// Build-time variants for same-box A/B runs (tools/ab_bench.sh): make CXXFLAGS+=-DC2V=<mask>.  The shipped build is all on.
+// Build-time variants for same-box A/B runs (tools/ab_bench.sh, tools/build_variants.sh): -DC2V=<mask>.  The shipped build is
+// everything but 16 (measured slower), 32 for the max model only (profiles/r04/ab_notes.txt).
 //   1  the decoder step hands y to the vector side itself (select mask, ey, y made under the split's SCC: ZH_DEC_STEP_Y)
 //   2  what a bit trains but the NEXT bit cannot read — mixer weights (their row changes with every bit), max's SSE entries
 //      and `mix2 8` weight — is computed one bit later, in the shadow of that bit's squash look-up (an s_load or ds_read
@@ -59,7 +60,7 @@ using namespace zhdev;
 //      round 4's per-bit stamps still find the wave waiting for (~95 cycles each) — are requested TWO bits ahead, four
 //      candidate rows each, and picked by the two bits decoded meanwhile
 #ifndef C2V
-#define C2V 15
+#define C2V 239
 #endif
 #define C2_TOUCH ((C2V & 8) != 0)
 
@@ -95,10 +96,11 @@ __device__ __forceinline__ int mul24_sv(int sc, int vec) {
 
 
 constexpr bool kYsel = (C2V & 1) != 0, kDefer = (C2V & 2) != 0, kRowReg = (C2V & 4) != 0;
-constexpr bool kOneWay = (C2V & 16) != 0 && kRowReg, kMatch2 = (C2V & 32) != 0, kRowsLate = (C2V & 64) != 0, kFar2 = (C2V & 128) != 0 && kYsel;
+constexpr bool kOneWay = (C2V & 16) != 0 && kRowReg, kRowsLate = (C2V & 64) != 0, kFar2 = (C2V & 128) != 0 && kYsel;
 
 template <class SP, bool PROF, int HELP, class LDS>
 __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
+  constexpr bool kMatch2 = (C2V & 32) != 0 && SP::id == 3;   // (same-box A/B: max + E8E9 +0.6 %, mid -0.7 %)
   uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t tprev = 0;
   const uint32_t lane = threadIdx.x & 63u;

@@ -225,14 +225,17 @@ __device__ void helper_wave(const ZhLaunch &L, const CmTabs &T, BLK &S, uint32_t
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     lds_st(&S.cmd_ack, cs);
 
-    // Byte messages run as a two-stage pipeline so that the LDS round trips of consecutive bytes
-    // overlap: stage 1 of byte u (read entry, read dt, train, write entry) is issued together with
-    // stage 2 of byte u-1 (stretch, squash, write the cached probability, report completion).
-    // LDS requests are served in issue order, so byte u reads the entries byte u-1 wrote.
-    bool pend = false, leave = false;                      // stage 2 of message u-1 outstanding
-    uint32_t p_nv = 0, p_off = 0;                          // per lane: trained entry, LDS offset of its p16
-    bool p_vis = false;
+    // A byte message is taken to its end at once: entry -> dt -> train -> write, then stretch -> squash of the trained entry ->
+    // cached probability -> report.  (Rounds 1-3 ran the second half together with the NEXT message's first half, to overlap
+    // their LDS round trips; completion of a byte then waited for the message behind it, wave B was two messages behind
+    // wave A as a rule, and round 4's stamps found A waiting for B on every byte whose window one of the last two bytes had
+    // used — 21 % of the bytes of text, ~560 cycles each, profiles/r04/stages_l1_miss.txt.  B has the time: it was busy
+    // ~580 of A's ~1 070 cycles per byte.)  Masked writes go through a per-lane address (unvisited lanes: a sink word):
+    // no exec-mask branches on the path.
+    bool leave = false;
     auto stretch_idx = [&](uint32_t nv) { const uint32_t xv = nv >> 17; return xv >= 16384 ? xv - 16384 : 16383 - xv; };
+    const bool second = (lane & 16) != 0;                  // lanes 0-15 (and their copies 32-47): first nibble (group 0); 16-31 (48-63): second nibble, group 16 + n1
+    const uint32_t l_sinkw = lds_off(&S.wsink[lane]);
     while (!leave) {
       const uint32_t m0 = uni(lds_ld(&S.ring[u & (kRing - 1)]));
       const bool have = (m0 >> 25) == ring_tag(u);
@@ -242,39 +245,26 @@ __device__ void helper_wave(const ZhLaunch &L, const CmTabs &T, BLK &S, uint32_t
         if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0)::"memory"); }
         sp = 0;
         const uint32_t c = (m0 >> 15) & 255, n1 = c >> 4, n2 = c & 15;
-        // lanes 0-15 (and their copies 32-47): entries of the first nibble (group 0);
-        // lanes 16-31 (48-63): second nibble, group 16 + n1
-        const bool second = (lane & 16) != 0;
         const uint32_t nib = second ? n2 : n1;
         const bool vis = lane < 32 && l15 != 0 && l15 == ((16 | nib) >> lsh_vis);
         const uint32_t eoff = second ? offB + slot * 1024 + n1 * 64 : offA + slot * 64;
+        const uint32_t p_off = second ? poffB + slot * 512 + p16b_pos(n1, l15) * 2 : poffA + slot * 32;
         // every lane reads (harmless for the unvisited ones); only the writes are masked
-        const uint32_t cm = *(lds_u32_p)eoff;                           // stage 1
-        const int shv = T.sh[stretch_idx(p_nv)];                        // stage 2 of the previous byte
+        const uint32_t cm = *(lds_u32_p)eoff;
         const uint32_t cnt = cm & 0x3ff;
         const int dtv = T.dt[cnt];
-        const uint32_t sqv = T.sq[((p_nv >> 17) >= 16384 ? shv : -shv) + 2048];
         const uint32_t yy = (nib >> lsh_y) & 1;
         const int err = (int)(yy * 32767) - (int)(cm >> 17);            // Predictor.train (Predictor.cs:1031-1036)
         const uint32_t nv = cm + (((uint32_t)err * (uint32_t)dtv) & 0xFFFFFC00u) + (cnt < limit);
-        if (vis) *(lds_u32_p)eoff = nv;
-        if (pend) {
-          if (p_vis) *(lds_u16_p)p_off = (uint16_t)(sqv * 2 + 1);
-          lds_order();
-          lds_put0(&S.b_seq, u);                                        // every message before u is complete
-        }
-        p_nv = nv; p_vis = vis; pend = true;
-        p_off = second ? poffB + slot * 512 + p16b_pos(n1, l15) * 2 : poffA + slot * 32;
+        *(lds_u32_p)(vis ? eoff : l_sinkw) = nv;
+        const int shv = T.sh[stretch_idx(nv)];
+        const uint32_t sqv = T.sq[((nv >> 17) >= 16384 ? shv : -shv) + 2048];
+        *(lds_u16_p)(vis ? p_off : l_sinkw) = (uint16_t)(sqv * 2 + 1);
         ++u;
+        lds_order();
+        lds_put0(&S.b_seq, u);                                          // every message before u is complete
         out_put(ob, c, lane);                              // PostProcessor PASS: the byte is the plaintext
         if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1)::"memory"); busy += tb1 - tb0; }
-      } else if (pend) {                                   // nothing new: finish the outstanding byte
-        const int shv = T.sh[stretch_idx(p_nv)];
-        const uint32_t sqv = T.sq[((p_nv >> 17) >= 16384 ? shv : -shv) + 2048];
-        if (p_vis) *(lds_u16_p)p_off = (uint16_t)(sqv * 2 + 1);
-        lds_order();
-        lds_put0(&S.b_seq, u);
-        pend = false;
       } else if (!have) {
         if (PROF) ++idle;
         if (++sp > kSpinSection) return;

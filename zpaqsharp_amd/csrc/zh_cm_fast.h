@@ -181,7 +181,10 @@
   "s_add_u32 s80, s89, s91\n\t"                                       \
   ZH_FAST_STEP("v250", "s91", "s80", N8)                              \
   ZH_FAST_EPILOGUE
-// SPIN_IN / SPIN_OK: nothing in the product build; the diagnostic build stamps the time wave A spends waiting for wave B here
+// SPIN_IN: nothing in the product build, a time stamp in the diagnostic one; SPIN_OK(S): where the spin leaves to when B has caught up —
+// straight back into the byte (product), or through a block that stamps the time wave A spent waiting (diagnostic)
+#define ZH_FAST_OK_DIRECT(S) ".Lzh_ok" #S "_%="
+#define ZH_FAST_OK_STAMPED(S) ".Lzh_okp" #S "_%="
 #define ZH_CM_FAST_COLD(S, E, N1, N2, N3, N4, N5, N6, N7, N8, SPIN_IN, SPIN_OK) \
   /* wave B is behind: re-read its progress counter a bounded number of times, then give up */ \
   ".Lzh_fresh" #S "_%=:\n\t"                                          \
@@ -193,14 +196,11 @@
   "v_readfirstlane_b32 %[bdone], v252\n\t"                            \
   "s_sub_u32 s89, %[t], %[bdone]\n\t"                                 \
   "s_cmp_gt_u32 s89, s83\n\t"                                         \
-  "s_cbranch_scc0 .Lzh_okp" #S "_%=\n\t"                              \
+  "s_cbranch_scc0 " SPIN_OK(S) "\n\t"                                 \
   "s_sub_u32 s80, s80, 1\n\t"                                         \
   "s_cmp_lg_u32 s80, 0\n\t"                                           \
   "s_cbranch_scc1 .Lzh_spin" #S "_%=\n\t"                             \
-  "s_branch .Lzh_slow_%=\n"                                           \
-  ".Lzh_okp" #S "_%=:\n\t"                                            \
-  SPIN_OK                                                             \
-  "s_branch .Lzh_ok" #S "_%=\n\t"                                     \
+  "s_branch .Lzh_slow_%=\n\t"                                         \
   ZH_FAST_RENORM(E)                                                   \
   ZH_FAST_RENORM(N1)                                                  \
   ZH_FAST_RENORM(N2)                                                  \
@@ -224,8 +224,8 @@
   ZH_CM_FAST_BYTE(b, 10, 11, 12, 13, 14, 15, 16, 17, 18)              \
   "s_branch .Lzh_byte_%=\n"                                           \
   /* ---- out of line ---- */                                         \
-  ZH_CM_FAST_COLD(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, "", "")               \
-  ZH_CM_FAST_COLD(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, "", "")      \
+  ZH_CM_FAST_COLD(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, "", ZH_FAST_OK_DIRECT)               \
+  ZH_CM_FAST_COLD(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, "", ZH_FAST_OK_DIRECT)      \
   /* ---- window miss, served without leaving the loop (round 4: the stage table of a miss, profiles/r04/stages_l1_miss_before.txt, \
      showed ~1 000 of its ~3 000 cycles between leaving this loop and re-entering it, and most of the rest waiting for wave B to \
      finish the byte before).  Victim = the first slot not used since message `thr` (empty slots carry 0, lanes that stand for no \
@@ -290,7 +290,7 @@
 // Diagnostic build (zh_decode_cm_prof): the same loop with the cycles spent in the spin (wave A waiting for wave B: a window
 // being swapped in, or B behind by more than the window's lag allowance) summed into spin_ (s96-s101 are scratch here).
 #define ZH_FAST_SPIN_IN "s_memtime s[96:97]\n\t"
-#define ZH_FAST_SPIN_OK "s_memtime s[98:99]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s98, s98, s96\n\ts_subb_u32 s99, s99, s97\n\ts_add_u32 s100, s100, s98\n\ts_addc_u32 s101, s101, s99\n\ts_add_u32 %[nspin], %[nspin], 1\n\t"
+#define ZH_FAST_SPIN_OK(S) ".Lzh_okp" #S "_%=:\n\ts_memtime s[98:99]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s98, s98, s96\n\ts_subb_u32 s99, s99, s97\n\ts_add_u32 s100, s100, s98\n\ts_addc_u32 s101, s101, s99\n\ts_add_u32 %[nspin], %[nspin], 1\n\ts_branch .Lzh_ok" #S "_%=\n\t"
 #define ZH_CM_FAST_LOOP_PROF(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_, thr_, nm_, mqa_, kb_, spin_lo_, spin_hi_, nspin_) \
   asm volatile(                                                       \
   "v_mov_b32_e32 v249, 0\n\t"                                         \
@@ -302,8 +302,10 @@
   ZH_CM_FAST_BYTE(a, 0, 1, 2, 3, 4, 5, 6, 7, 8)                       \
   ZH_CM_FAST_BYTE(b, 10, 11, 12, 13, 14, 15, 16, 17, 18)              \
   "s_branch .Lzh_byte_%=\n"                                           \
-  ZH_CM_FAST_COLD(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, ZH_FAST_SPIN_IN, ZH_FAST_SPIN_OK)              \
-  ZH_CM_FAST_COLD(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, ZH_FAST_SPIN_IN, ZH_FAST_SPIN_OK)     \
+  ZH_CM_FAST_COLD(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, ZH_FAST_SPIN_IN, ZH_FAST_OK_STAMPED)              \
+  ZH_CM_FAST_COLD(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, ZH_FAST_SPIN_IN, ZH_FAST_OK_STAMPED)     \
+  ZH_FAST_SPIN_OK(a)                                                  \
+  ZH_FAST_SPIN_OK(b)                                                  \
   /* ---- window miss, served without leaving the loop (round 4: the stage table of a miss, profiles/r04/stages_l1_miss_before.txt, \
      showed ~1 000 of its ~3 000 cycles between leaving this loop and re-entering it, and most of the rest waiting for wave B to \
      finish the byte before).  Victim = the first slot not used since message `thr` (empty slots carry 0, lanes that stand for no \
