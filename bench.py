@@ -325,7 +325,13 @@ def cpu_sweep(oracle, pieces, plain_each, counts):
 
 
 def sweep_counts(share):
+    """8 threads up to every core the process may run on — or, where a cgroup CPU quota is set, up to four times the
+    quota (past that the sweep only measures the quota: the r04 boxes give 16 cores' worth of 256, L1 peaks at 32
+    threads and mid at 16, and 256 threads of the mid model take a minute to say so)."""
     top = share["affinity_cores"] or share["host_logical_cores"] or 1
+    q = share.get("cgroup_cpu_quota_cores")
+    if q:
+        top = min(top, max(32, int(4 * q)))
     return sorted({c for c in (8, 16, 32, 64, 128, top) if c <= top})
 
 

@@ -81,6 +81,8 @@ struct alignas(16) C2LdsT {
   uint32_t hspec[HELP == 2 ? kSpecHMax : HELP == 1 ? kSpecH : 1][16];      // H[d] after HCOMP(candidate)
   v4u_ rowst[HELP == 1 ? kSpecUnits : 1][3][16];   // the three candidate hash rows of every ICM / ISSE for c8 = 1
   uint32_t mixst[HELP == 1 ? 2 : 1][16][16];       // the mixer rows for c8 = 1
+  v4u_ selrow[HELP == 1 ? kSpecUnits : 1][16];     // C2_FINDB: the row Predictor.find settles on for each unit and candidate ...
+  uint32_t seloff[HELP == 1 ? kSpecUnits : 1][16]; // ... and its place in the hash table (the helper wave ran the three compares and the victim choice)
   uint32_t mb_nib, mb_byte, mb_ready;         // A -> B: seq << 8 | first nibble / byte;  B -> A: seq whose staging is complete
   uint32_t mb_cmd, mb_ack, mb_model;          // A -> B: block start / end / exit
 #ifdef ZH_WITH_CHAIN3
@@ -279,7 +281,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
     const uint32_t arena_bytes = uni((uint32_t)M->arena_bytes);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slot_mem, 0, (int)arena_bytes, 0x00020000);
     // this lane's units: u = grp, grp + 4 (rows of unit u for candidate `cand`)
-    uint32_t u_hto[RN], u_mask[RN], u_comp[RN];
+    uint32_t u_hto[RN], u_mask[RN], u_comp[RN], u_sb2[RN];
     bool u_on[RN];
 #pragma unroll
     for (uint32_t r = 0; r < RN; ++r) {
@@ -289,7 +291,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
 #pragma unroll
       for (uint32_t k = 0; k < NU; ++k) if (k == u) ci = c2_unit_comp<SP>(k);
       const ZhComp *cp = &M->comp[ci];
-      u_comp[r] = ci; u_hto[r] = (uint32_t)cp->ht_off; u_mask[r] = cp->ht_mask;
+      u_comp[r] = ci; u_hto[r] = (uint32_t)cp->ht_off; u_mask[r] = cp->ht_mask; u_sb2[r] = (uint32_t)cp->arg[0] + 2u;
     }
     uint32_t mx_base[2] = {0, 0}, mx_size1[2] = {0, 0};
 #pragma unroll
@@ -331,12 +333,14 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       if constexpr (ROWS) {
       // ---- rows of the first nibble of the next byte (c8 = 1): Predictor.find's three candidates per component
       v4u rr[2][3];
+      uint32_t cxts[2] = {0, 0};
 #pragma unroll
       for (uint32_t r = 0; r < 2; ++r) {
         uint32_t hval = 0;
 #pragma unroll
         for (uint32_t d = 0; d < NH; ++d) if ((u_comp[r] & (NH - 1u)) == d) hval = (uint32_t)sh[d];
         const uint32_t cxt = hval + 16u;
+        cxts[r] = cxt;
         const uint32_t h0 = (cxt * 16u) & (u_mask[r] - 15u);
         const uint32_t vo = u_on[r] ? u_hto[r] + h0 : kOob;
         rr[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
@@ -382,6 +386,23 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
         if (u_on[r]) {
 #pragma unroll
           for (uint32_t k = 0; k < 3; ++k) *(lds_u4_p)lds_off(&S.rowst[grp + 4u * r][k][cand]) = rr[r][k];
+#ifdef C2_FINDB
+          if (C2_FINDB) {
+            // Predictor.find (Predictor.cs:550-567) on the three probes, here instead of at the decoder wave's byte boundary:
+            // check compare, then the lowest-priority row as the victim (ties as the reference breaks them)
+            const uint32_t chk = (cxts[r] >> u_sb2[r]) & 255u;
+            const uint32_t h0 = (cxts[r] * 16u) & (u_mask[r] - 15u);
+            const v4u &r0 = rr[r][0], &r1 = rr[r][1], &r2 = rr[r][2];
+            const bool m0 = (r0.x & 255u) == chk, m1 = (r1.x & 255u) == chk, m2 = (r2.x & 255u) == chk;
+            const uint32_t p0 = (r0.x >> 8) & 255u, p1 = (r1.x >> 8) & 255u, p2 = (r2.x >> 8) & 255u;
+            const uint32_t victim = (p0 <= p1 && p0 <= p2) ? h0 : p1 < p2 ? (h0 ^ 16u) : (h0 ^ 32u);
+            const uint32_t sel = m0 ? h0 : m1 ? (h0 ^ 16u) : m2 ? (h0 ^ 32u) : victim;
+            const v4u fresh = {chk, 0, 0, 0};
+            const v4u row = m0 ? r0 : m1 ? r1 : m2 ? r2 : fresh;
+            *(lds_u4_p)lds_off(&S.selrow[grp + 4u * r][cand]) = row;
+            S.seloff[grp + 4u * r][cand] = sel;
+          }
+#endif
         }
       }
 #pragma unroll

@@ -38,7 +38,7 @@ using namespace zhdev;
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 
 // Build-time variants for same-box A/B runs (tools/ab_bench.sh, tools/build_variants.sh): -DC2V=<mask>.  The shipped build is
-// everything but 16 (measured slower), 32 for the max model only (profiles/r04/ab_notes.txt).
+// everything but 16 (measured slower), 32 for the max model only (profiles/r04/ab_notes.txt): 1007.
 //   1  the decoder step hands y to the vector side itself (select mask, ey, y made under the split's SCC: ZH_DEC_STEP_Y)
 //   2  what a bit trains but the NEXT bit cannot read — mixer weights (their row changes with every bit), max's SSE entries
 //      and `mix2 8` weight — is computed one bit later, in the shadow of that bit's squash look-up (an s_load or ds_read
@@ -59,10 +59,19 @@ using namespace zhdev;
 // 128  (mid, with 1) the weights of bits 6 and 7 — rows 64-255 of the byte's block, a new line with every bit, the only ones
 //      round 4's per-bit stamps still find the wave waiting for (~95 cycles each) — are requested TWO bits ahead, four
 //      candidate rows each, and picked by the two bits decoded meanwhile
+// 256  (min, mid) Predictor.find at the byte boundary done by the HELPER wave for its 16 candidates (check compare and victim
+//      choice on the three probes it holds anyway): the decoder wave reads one row and its place instead of three rows,
+//      a patch and the selection — unless a row it evicted after the helper's loads lies in the same bucket (then the
+//      round-3 path)
+// 512  the byte boundary reads the helper's "ready" word and everything it staged for the byte in ONE batch of LDS reads and
+//      checks the word afterwards (the helper is ready ~550 cycles early, round-4 stamps): one LDS round trip where round 3
+//      had three in a row (wait for ready, then h[], then the rows)
 #ifndef C2V
-#define C2V 239
+#define C2V 1007
 #endif
 #define C2_TOUCH ((C2V & 8) != 0)
+#define C2_FINDB ((C2V & 256) != 0)
+#define C2_SPECRD ((C2V & 512) != 0)
 
 #include "zh_c2_common.h"
 
@@ -886,6 +895,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
 
           // ---- byte boundary: MATCH (Predictor.cs:391-410), HCOMP, h[], rows of the next byte
           {
+            v4u sg_row = {0, 0, 0, 0}; uint32_t sg_sel = 0; int sg_mw[2] = {0, 0};   // what the helper wave staged for this byte's value
             if (SP::match_lane >= 0) {                   // still with the h[i] of the byte just coded (update0 runs before z.run)
               __builtin_amdgcn_raw_buffer_store_b8((uint8_t)c, rsrc, l_match ? hto + (m_limit & ht_mask) : kOob, 0, 0);
               m_limit = l_match ? (m_limit + 1) & ht_mask : m_limit;
@@ -895,10 +905,30 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               // ---- two-wave form: the helper wave ran HCOMP for this byte's value among 16 (and staged what follows)
               c2_put0(&S.mb_byte, bseq << 8 | (uint32_t)c);
               C2_STAMP(11);
-              if (helper_ok) helper_ok = c2_wait(&S.mb_ready, bseq);
+              const uint32_t lo_ = (uint32_t)c & 15u, un_ = unit < (uint32_t)kSpecUnits ? unit : 0u;
+              auto read_staged = [&]() __attribute__((always_inline)) {
+                hv = S.hspec[lane & ((1u << SP::hh) - 1u)][lo_];
+                if (HELP == 1 && C2_FINDB) { sg_row = *(lds_u4_p)lds_off(&S.selrow[un_][lo_]); sg_sel = S.seloff[un_][lo_]; }
+                if (HELP == 1) {
+#pragma unroll
+                  for (uint32_t q = 0; q < SP::nmix; ++q) { const uint32_t jj = lane - SP::mix_j0[q]; sg_mw[q] = (int)S.mixst[q][lo_][jj & 15u]; }
+                }
+              };
+              if (C2_SPECRD) {
+                const uint32_t rdy_v = __hip_atomic_load(&S.mb_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");             // (the flag first: what is read behind it is what the flag vouches for)
+                read_staged();
+                if (UNLIKELY(uni(rdy_v) != bseq)) {        // not yet: wait, then read again
+                  if (helper_ok) helper_ok = c2_wait(&S.mb_ready, bseq);
+                  asm volatile("" ::: "memory");
+                  read_staged();
+                }
+              } else {
+                if (helper_ok) helper_ok = c2_wait(&S.mb_ready, bseq);
+                asm volatile("" ::: "memory");
+                read_staged();
+              }
               if (!helper_ok) { status = -24; break; }       // ZPAQHIP_E_HIP: the helper wavefront stopped answering (cannot happen by design)
-              asm volatile("" ::: "memory");
-              hv = S.hspec[lane & ((1u << SP::hh) - 1u)][(uint32_t)c & 15u];
               ++bseq;
             }
             if (HELP == 1) {
@@ -912,23 +942,46 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
                 pr.chk = (cxt >> sizebits2) & 255;
                 pr.h0 = (cxt * 16u) & (ht_mask - 15u);
                 const uint32_t un = unit < (uint32_t)kSpecUnits ? unit : 0u;
-                pr.r0 = *(lds_u4_p)lds_off(&S.rowst[un][0][lo]);
-                pr.r1 = *(lds_u4_p)lds_off(&S.rowst[un][1][lo]);
-                pr.r2 = *(lds_u4_p)lds_off(&S.rowst[un][2][lo]);
+                if (!C2_FINDB) {
+                  pr.r0 = *(lds_u4_p)lds_off(&S.rowst[un][0][lo]);
+                  pr.r1 = *(lds_u4_p)lds_off(&S.rowst[un][1][lo]);
+                  pr.r2 = *(lds_u4_p)lds_off(&S.rowst[un][2][lo]);
+                }
               }
 #pragma unroll
               for (uint32_t q = 0; q < SP::nmix; ++q) {
                 mix_set(q, rdlane(hv, SP::mix_lane[q]));
                 mrow[q] = mix_row(q, 1u);
                 const uint32_t jj = lane - SP::mix_j0[q];
-                mw[q] = jj < SP::mix_m[q] ? (int)S.mixst[q][lo][jj & 15u] : 0;
+                mw[q] = jj < SP::mix_m[q] ? sg_mw[q] : 0;
               }
               if (SP::match_lane >= 0) {
                 match_boundary((uint32_t)c);
                 cm_pre = __builtin_amdgcn_raw_buffer_load_b32(rsrc, l_match ? cmo + (hv & cm_mask) * 4u : kOob, 0, 0);
               }
               C2_STAMP(6);
-              rows_finish2(pr, old1, old1_off, old1_valid, old, old_off, old_valid, SP::guard_rows);
+              bool taken = false;
+              if (C2_FINDB) {
+                const bool near = (old1_valid && ((old1_off ^ pr.h0) & ~48u) == 0) || (old_valid && ((old_off ^ pr.h0) & ~48u) == 0);
+                if (LIKELY(__ballot(near) == 0)) {       // nothing this wave wrote late lies in a probed bucket: the helper's answer stands
+                  const v4u row = sg_row;
+                  const uint32_t sel = sg_sel;
+                  *(lds_u4_p)lds_off(&S.slot[lane]) = row;
+                  rowoff = sel; rowvalid = true;
+                  row_x = l_ii ? row.x : 0u;
+                  if (kRowReg) { row_q1 = l_ii ? row.y : 0u; row_q2 = l_ii ? row.z : 0u; row_q3 = l_ii ? row.w : 0u; }
+                  taken = true;
+                }
+              }
+              if (!taken) {
+                if (C2_FINDB) {
+                  const uint32_t un = unit < (uint32_t)kSpecUnits ? unit : 0u;
+                  pr.r0 = *(lds_u4_p)lds_off(&S.rowst[un][0][lo]);
+                  pr.r1 = *(lds_u4_p)lds_off(&S.rowst[un][1][lo]);
+                  pr.r2 = *(lds_u4_p)lds_off(&S.rowst[un][2][lo]);
+                }
+                rows_finish2(pr, old1, old1_off, old1_valid, old, old_off, old_valid, SP::guard_rows);
+              }
               asm volatile("" ::: "memory");
               C2_STAMP(7);
             } else {
