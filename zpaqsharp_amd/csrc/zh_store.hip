@@ -52,6 +52,7 @@ struct Lz {
 struct alignas(16) StoreLds {
   uint8_t ring[kRing];
   uint32_t win[64];                                     // the register window's 256 bytes
+  uint8_t csink[64];                                    // lazy2 fast loop: where the lanes beyond a copy's length read and write (no exec switch)
   uint32_t words[64];                                   // operands of the block's program (before: the block's description)
   uint32_t wpos, fpos;                                  // parser: bytes written into the ring; flusher: bytes moved out (per block)
   uint32_t cmd, ack;                                    // parser -> flusher: sequence << 2 | kCmd*; flusher: last command seen
@@ -189,7 +190,11 @@ __device__ void store_flusher(const ZhLaunch &L, StoreLds &S, uint32_t lane) {
 // crowd the scalar registers of this loop (the first form spilled 87 of them).
 // ---------------------------------------------------------------------------------------------------------------
 
-__device__ __attribute__((noinline)) void lz_window(StoreLds &S, Lz &Z, uint32_t cur, const uint8_t *Mp, uint32_t lane) {
+__device__ __attribute__((noinline)) void lz_window(StoreLds &S, Lz &Z, uint32_t cur, const uint8_t *Mp, uint32_t lane, uint64_t *dbg) {
+#ifdef ST_PROF
+  uint64_t pt0, pt1, pf0 = 0, pf1 = 0, p_far = 0; uint32_t n_a0 = 0, n_a = 0, n_b = 0, n_far = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt0)::"memory");
+#endif
   const uint32_t ring = lds_off(S.ring);
   uint32_t k = uni(Z.k);
   const uint32_t k0 = k, avail = uni(Z.avail), left = uni(Z.left), kdisc = uni(Z.kdisc);
@@ -262,6 +267,9 @@ __device__ __attribute__((noinline)) void lz_window(StoreLds &S, Lz &Z, uint32_t
         // from M, further back than the ring (or from before the segment): the flusher has passed the source and the
         // copy does not reach its own output
         const uint32_t p = ptr - dist;
+#ifdef ST_PROF
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pf0)::"memory"); ++n_far;
+#endif
         for (uint32_t base = 0; base < piece; base += 256) {
           uint32_t v[4];
 #pragma unroll
@@ -269,6 +277,9 @@ __device__ __attribute__((noinline)) void lz_window(StoreLds &S, Lz &Z, uint32_t
 #pragma unroll
           for (int k = 0; k < 4; ++k) { const uint32_t j = base + 64u * k + lane; if (j < piece) *(lds_u8_p)(ring + ((wp + j) & kRM)) = (uint8_t)v[k]; }
         }
+#ifdef ST_PROF
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pf1)::"memory"); p_far += pf1 - pf0;
+#endif
         wp += piece;
       } else {
         // the rest (a source the flusher has not reached, distance 0 = M rewritten in place, a short period over
@@ -345,7 +356,143 @@ __device__ __attribute__((noinline)) void lz_window(StoreLds &S, Lz &Z, uint32_t
         bits = (uint32_t)qq & (nb >= 32u ? 0xFFFFFFFFu : (1u << nb) - 1u);
         stale = false;
       };
+      const uint32_t v_sink = lds_off(S.csink) + lane;
       while (k < kend && !lost) {
+        // (A0) THE COMMON CODE, in assembly (round 4).  On text 96 % of the codes are matches of 4-15 bytes (two length pairs
+        // at most) from inside the ring that do not overlap their own output.  The general form (A) below is ~300
+        // instructions and ~20 taken branches for one (1 850 cycles per code at 2.2 GB/s: the parser wave is bound by its own
+        // instruction stream, nothing else); the compiler's rendering of a straight-line C++ form still took ~870 cycles
+        // (mask juggling for every condition, the LDS read waited for at once).  Here: ~85 instructions per code, the
+        // conditions as compare + not-taken branch, the copy WRITTEN ONE CODE LATE (the byte a lane has read for code i
+        // goes into the ring in front of the read of code i + 1 — LDS serves a wave's requests in order, so that read sees
+        // it — and the parse of code i + 1 runs under the LDS round trip), lanes beyond the length on a sink byte instead of
+        // an exec switch.  Same arithmetic and byte-arrival accounting as (A); whatever is not this kind of code — a
+        // literal run, a longer length, a source beyond the ring or overlapping its output, no room in the ring, the chunk's
+        // end, 1 KiB written since the flusher was last told — changes no state and leaves the loop.
+        if (LIKELY(st == 0u && rb == 0u)) {
+          uint32_t took = 0;
+          asm volatile(
+              "v_mov_b32_e32 v251, %[snk]\n\t"          /* pending write: address (sink), value */
+              "v_mov_b32_e32 v250, 0\n"
+              ".Lz2_loop_%=:\n\t"
+              "s_sub_u32 s80, %[kend], %[k]\n\t"
+              "s_cmp_lt_u32 s80, 9\n\t"
+              "s_cbranch_scc1 .Lz2_out_%=\n\t"
+              "s_sub_u32 s80, %[k], %[kdisc]\n\t"
+              "s_lshl_b32 s80, s80, 3\n\t"
+              "s_cmp_lt_u32 s80, %[nb]\n\t"
+              "s_cbranch_scc1 .Lz2_out_%=\n\t"
+              "s_lshl_b32 s80, %[k], 3\n\t"
+              "s_sub_u32 s80, s80, %[nb]\n\t"           /* window bit position of the first unused bit */
+              "s_lshr_b32 s81, s80, 5\n\t"
+              "s_add_u32 s83, s81, 1\n\t"
+              "s_and_b32 s82, s80, 31\n\t"
+              "s_add_u32 s88, %[k], 1\n\t"              /* kv0: stage 0 has taken a byte */
+              "s_add_u32 s89, %[nb], 3\n\t"             /* nv0 = n + 8 - 5 (`mm mmm`) */
+              "s_cmp_le_u32 s89, 2\n\t"
+              "s_cselect_b32 s90, 1, 0\n\t"
+              "v_readlane_b32 s84, %[cur], s81\n\t"
+              "v_readlane_b32 s85, %[cur], s83\n\t"
+              "s_add_u32 s88, s88, s90\n\t"
+              "s_lshl_b32 s90, s90, 3\n\t"
+              "s_add_u32 s89, s89, s90\n\t"
+              "s_lshr_b64 s[84:85], s[84:85], s82\n\t"  /* q: at least 33 valid bits */
+              "s_and_b32 s86, s84, 3\n\t"
+              "s_cmp_eq_u32 s86, 0\n\t"
+              "s_cbranch_scc1 .Lz2_out_%=\n\t"          /* 00: a literal run */
+              "s_sub_u32 s86, s86, 1\n\t"
+              "s_lshl_b32 s86, s86, 3\n\t"
+              "s_bfe_u32 s87, s84, 0x30002\n\t"
+              "s_add_u32 s86, s86, s87\n\t"             /* m: offset bits */
+              "s_bfe_u32 s91, s84, 0x30005\n\t"         /* first length triple */
+              "s_bitcmp1_b32 s91, 0\n\t"
+              "s_cbranch_scc1 .Lz2_two_%=\n\t"
+              "s_lshr_b32 s92, s91, 1\n\t"
+              "s_add_u32 s92, s92, 4\n\t"               /* length 4..7 */
+              "s_sub_u32 s89, s89, 3\n\t"
+              "s_mov_b32 s93, 8\n"
+              ".Lz2_got_%=:\n\t"
+              "s_sub_u32 s94, s86, s89\n\t"             /* stage 2: bytes taken until n >= m */
+              "s_add_u32 s94, s94, 7\n\t"
+              "s_lshr_b32 s94, s94, 3\n\t"
+              "s_cmp_lt_u32 s89, s86\n\t"
+              "s_cselect_b32 s94, s94, 0\n\t"
+              "s_add_u32 s88, s88, s94\n\t"
+              "s_lshl_b32 s94, s94, 3\n\t"
+              "s_add_u32 s89, s89, s94\n\t"
+              "s_sub_u32 s89, s89, s86\n\t"
+              "s_cmp_gt_u32 s88, %[kend]\n\t"
+              "s_cbranch_scc1 .Lz2_out_%=\n\t"
+              "s_lshr_b64 s[94:95], s[84:85], s93\n\t"
+              "s_bfm_b32 s95, s86, 0\n\t"
+              "s_and_b32 s94, s94, s95\n\t"
+              "s_lshl_b32 s95, 1, s86\n\t"
+              "s_add_u32 s94, s94, s95\n\t"
+              "s_and_b32 s94, s94, %[mmask]\n\t"        /* distance (M is addressed modulo its size) */
+              "s_cmp_lt_u32 s94, s92\n\t"
+              "s_cbranch_scc1 .Lz2_out_%=\n\t"          /* would read its own output */
+              "s_sub_u32 s95, %[wp], %[segb]\n\t"
+              "s_min_u32 s95, s95, 0x1ffc0\n\t"
+              "s_cmp_lt_u32 s95, s94\n\t"
+              "s_cbranch_scc1 .Lz2_out_%=\n\t"          /* from before the segment, or from beyond the ring */
+              "s_add_u32 s96, %[wp], s92\n\t"
+              "s_sub_u32 s95, s96, %[fpos]\n\t"
+              "s_cmp_gt_u32 s95, 0x17000\n\t"
+              "s_cbranch_scc1 .Lz2_out_%=\n\t"          /* the flusher is too far behind */
+              "s_sub_u32 s95, %[wp], s94\n\t"
+              "v_add_u32_e32 v252, s95, %[lane]\n\t"
+              "v_add_u32_e32 v253, %[wp], %[lane]\n\t"
+              "v_and_b32_e32 v252, 0x1ffff, v252\n\t"
+              "v_and_b32_e32 v253, 0x1ffff, v253\n\t"
+              "v_cmp_gt_u32_e32 vcc, s92, %[lane]\n\t"
+              "v_add_u32_e32 v252, %[ring], v252\n\t"
+              "v_add_u32_e32 v253, %[ring], v253\n\t"
+              "v_cndmask_b32_e32 v252, %[snk], v252, vcc\n\t"
+              "ds_write_b8 v251, v250\n\t"              /* the code before */
+              "v_cndmask_b32_e32 v251, %[snk], v253, vcc\n\t"
+              "ds_read_u8 v250, v252\n\t"
+              "s_mov_b32 %[wp], s96\n\t"
+              "s_mov_b32 %[k], s88\n\t"
+              "s_mov_b32 %[nb], s89\n\t"
+              "s_mov_b32 %[mb], s86\n\t"
+              "s_mov_b32 %[ln], s92\n\t"
+              "s_add_u32 %[took], %[took], 1\n\t"
+              "s_sub_u32 s95, s96, %[wpub]\n\t"
+              "s_cmp_lt_u32 s95, 0x400\n\t"
+              "s_cbranch_scc1 .Lz2_loop_%=\n\t"
+              "s_branch .Lz2_out_%=\n"
+              ".Lz2_two_%=:\n\t"                         /* 1b: a second triple decides */
+              "s_sub_u32 s89, s89, 2\n\t"
+              "s_cmp_le_u32 s89, 2\n\t"
+              "s_cselect_b32 s90, 1, 0\n\t"
+              "s_add_u32 s88, s88, s90\n\t"
+              "s_lshl_b32 s90, s90, 3\n\t"
+              "s_add_u32 s89, s89, s90\n\t"
+              "s_bfe_u32 s93, s84, 0x30007\n\t"
+              "s_bitcmp1_b32 s93, 0\n\t"
+              "s_cbranch_scc1 .Lz2_out_%=\n\t"          /* three pairs or more: (A) */
+              "s_bfe_u32 s92, s91, 0x10001\n\t"
+              "s_add_u32 s92, s92, 2\n\t"
+              "s_lshl_b32 s92, s92, 2\n\t"
+              "s_lshr_b32 s93, s93, 1\n\t"
+              "s_add_u32 s92, s92, s93\n\t"             /* length 8..15 */
+              "s_sub_u32 s89, s89, 3\n\t"
+              "s_mov_b32 s93, 10\n\t"
+              "s_branch .Lz2_got_%=\n"
+              ".Lz2_out_%=:\n\t"
+              "ds_write_b8 v251, v250\n\t"              /* nothing stays pending outside */
+              "s_waitcnt lgkmcnt(0)\n\t"
+              : [k] "+s"(k), [nb] "+s"(nb), [wp] "+s"(wp), [mb] "+s"(mbits), [ln] "+s"(len), [took] "+s"(took)
+              : [kend] "s"(kend), [kdisc] "s"(kdisc), [mmask] "s"(mmask), [segb] "s"(seg_base), [fpos] "s"(fpos_seen), [wpub] "s"(wpub),
+                [cur] "v"(cur), [lane] "v"(lane), [ring] "v"(ring), [snk] "v"(v_sink)
+              : "memory", "scc", "vcc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92",
+                "s93", "s94", "s95", "s96", "v250", "v251", "v252", "v253");
+          if (took) {
+            stale = true;
+            if (wp - wpub >= 1024u) publish();
+            continue;                                     // (the loop's own test first: the window may be used up)
+          }
+        }
         if (st == 0u && kend - k >= 16u && 8u * (k - kdisc) >= nb) {
           const uint32_t bp = 8u * k - nb;                             // window bit position of the first unused bit
           const uint32_t ix = bp >> 5, sh = bp & 31u;
@@ -377,6 +524,9 @@ __device__ __attribute__((noinline)) void lz_window(StoreLds &S, Lz &Z, uint32_t
             if (!odd && kv <= kend && ln <= (1u << 24)) {
               r5 = rb ? rr : r5; mbits = mb;
               if (ln) copy_match(a, ln);
+#ifdef ST_PROF
+              ++n_a;
+#endif
               len = ln; k = kv; nb = nv; stale = true;
               if (wp - wpub >= 1024u) publish();
               continue;
@@ -429,6 +579,9 @@ __device__ __attribute__((noinline)) void lz_window(StoreLds &S, Lz &Z, uint32_t
           if (wp - wpub >= 1024u) publish();
           continue;
         }
+#ifdef ST_PROF
+        ++n_b;
+#endif
         bits += next_byte() << (nb & 31u);
         nb += 8u;
         if (st == 0u) {                                                  // expect a new code
@@ -471,6 +624,15 @@ __device__ __attribute__((noinline)) void lz_window(StoreLds &S, Lz &Z, uint32_t
     }
   }
 
+#ifdef ST_PROF
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt1)::"memory");
+  if (lane == 0 && dbg) {
+    atomicAdd((unsigned long long *)&dbg[0], (unsigned long long)(pt1 - pt0)); atomicAdd((unsigned long long *)&dbg[1], 1ull);
+    atomicAdd((unsigned long long *)&dbg[2], (unsigned long long)n_a0); atomicAdd((unsigned long long *)&dbg[3], (unsigned long long)n_a);
+    atomicAdd((unsigned long long *)&dbg[4], (unsigned long long)n_b); atomicAdd((unsigned long long *)&dbg[5], (unsigned long long)n_far);
+    atomicAdd((unsigned long long *)&dbg[6], (unsigned long long)p_far);
+  }
+#endif
   if (lane == 0) {
     Z.k = k; Z.left = left - (k - k0);
     Z.nb = nb; Z.bits = bits; Z.st = st; Z.len = len; Z.mbits = mbits; Z.r5 = r5; Z.off = off;
@@ -775,7 +937,7 @@ extern "C" __global__ __launch_bounds__(128) void zh_decode_store(ZhLaunch L) {
             S.z.wp = wp; S.z.wpub = wpub; S.z.fpos_seen = fpos_seen; S.z.seg_base = seg_base;
           }
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          lz_window(S, S.z, r.in.cur, Mp, lane);
+          lz_window(S, S.z, r.in.cur, Mp, lane, L.debug);
           r.in.k = uni(S.z.k); r.left = uni(S.z.left);
           wp = uni(S.z.wp); wpub = uni(S.z.wpub); fpos_seen = uni(S.z.fpos_seen);
           const uint32_t fl = uni(S.z.flags);
