@@ -129,7 +129,8 @@
 // the EOS flag, N1..N8 = label numbers of the eight bit steps.  The loop body is laid out TWICE (a taken s_branch costs a lone
 // wave ~21 cycles, tools/ubench/salu_bench: the second copy falls through from the first and only it branches back; same-box
 // A/B: one copy 564.6, two 571.6, four 568.7 MB/s).
-#define ZH_CM_FAST_BYTE(S, E, N1, N2, N3, N4, N5, N6, N7, N8)         \
+#define ZH_CM_FAST_BYTE(S, E, N1, N2, N3, N4, N5, N6, N7, N8, H0, H1, H2, H3) \
+  H0                                                                  \
   /* window lookup: lane s of `tag` holds the window id cached in slot s */ \
   "s_bfe_u32 s81, %[h0], %[bfe]\n\t"                                  \
   "v_cmp_eq_u32_e32 vcc, s81, %[tag]\n\t"                             \
@@ -143,6 +144,7 @@
   "s_cmp_gt_u32 s89, s83\n\t"                                         \
   "s_cbranch_scc1 .Lzh_fresh" #S "_%=\n"                              \
   ".Lzh_ok" #S "_%=:\n\t"                                             \
+  H1                                                                  \
   /* cached probabilities: lane j <- node j of the first nibble; lane (q, j) <- node j of groups q, q+4, q+8, q+12. */ \
   /* Issued before the remaining tests so that their latency is covered; a slow exit waits for them. */ \
   "v_lshl_add_u32 v252, s82, 5, %[la]\n\t"                            \
@@ -161,6 +163,7 @@
   "s_cbranch_scc1 .Lzh_rn" #E "_%=\n"                                 \
   ".Lzh_bk" #E "_%=:\n\t"                                             \
   "s_waitcnt lgkmcnt(0)\n\t"                                          \
+  H2                                                                  \
   ZH_FAST_STEP1("v249", "s90", "1", N1)                               \
   ZH_FAST_STEP("v249", "s90", "s90", N2)                              \
   ZH_FAST_STEP("v249", "s90", "s90", N3)                              \
@@ -180,6 +183,7 @@
   ZH_FAST_STEP("v250", "s91", "s80", N7)                              \
   "s_add_u32 s80, s89, s91\n\t"                                       \
   ZH_FAST_STEP("v250", "s91", "s80", N8)                              \
+  H3                                                                  \
   ZH_FAST_EPILOGUE
 // SPIN_IN: nothing in the product build, a time stamp in the diagnostic one; SPIN_OK(S): where the spin leaves to when B has caught up —
 // straight back into the byte (product), or through a block that stamps the time wave A spent waiting (diagnostic)
@@ -220,8 +224,8 @@
   "s_branch .Lzh_byte_%=\n\t"   /* over the alignment padding: up to 63 s_nop, ~150 cycles per entry on average, and a window miss enters anew */ \
   ".p2align 8\n"                                                      \
   ".Lzh_byte_%=:\n\t"                                                 \
-  ZH_CM_FAST_BYTE(a, 0, 1, 2, 3, 4, 5, 6, 7, 8)                       \
-  ZH_CM_FAST_BYTE(b, 10, 11, 12, 13, 14, 15, 16, 17, 18)              \
+  ZH_CM_FAST_BYTE(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, "", "", "", "")       \
+  ZH_CM_FAST_BYTE(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, "", "", "", "") \
   "s_branch .Lzh_byte_%=\n"                                           \
   /* ---- out of line ---- */                                         \
   ZH_CM_FAST_COLD(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, "", ZH_FAST_OK_DIRECT)               \
@@ -289,23 +293,73 @@
     "s91", "s92", "s94", "v249", "v250", "v251", "v252")
 // Diagnostic build (zh_decode_cm_prof): the same loop with the cycles spent in the spin (wave A waiting for wave B: a window
 // being swapped in, or B behind by more than the window's lag allowance) summed into spin_ (s96-s101 are scratch here).
+// -DZH_L1_STAGE=n (n = 1..4) turns the diagnostic loop into a STAGE build instead: the cycles between two points of the byte
+// (1: byte start -> lag test passed; 2: -> probabilities back from LDS, i.e. address arithmetic, the two reads, the chunk and
+// EOS tests and the wait; 3: -> the eight bit steps; 4: -> epilogue and loop branch, up to the next byte's start), two
+// s_memtime per byte without a wait of their own (each is read behind a wait the byte has anyway) and four scalar
+// instructions to add the difference up: ~28 cycles per byte of distortion, one stage per build so that it stays that small.
+#ifndef ZH_L1_STAGE
+#define ZH_L1_STAGE 0
+#endif
+#define ZH_STG_A "s_memtime s[96:97]\n\t"
+#define ZH_STG_B "s_memtime s[98:99]\n\t"
+#define ZH_STG_ACC "s_sub_u32 s98, s98, s96\n\ts_subb_u32 s99, s99, s97\n\ts_add_u32 s100, s100, s98\n\ts_addc_u32 s101, s101, s99\n\t"
+#if ZH_L1_STAGE == 1
+#define ZH_STG_H0 ZH_STG_A
+#define ZH_STG_H1 ZH_STG_B
+#define ZH_STG_H2 ZH_STG_ACC
+#define ZH_STG_H3 ""
+#elif ZH_L1_STAGE == 2
+#define ZH_STG_H0 ""
+#define ZH_STG_H1 ZH_STG_A
+#define ZH_STG_H2 ZH_STG_B
+#define ZH_STG_H3 "s_waitcnt lgkmcnt(0)\n\t" ZH_STG_ACC
+#elif ZH_L1_STAGE == 3
+#define ZH_STG_H0 ""
+#define ZH_STG_H1 ""
+#define ZH_STG_H2 ZH_STG_ACC ZH_STG_A
+#define ZH_STG_H3 ZH_STG_B
+#elif ZH_L1_STAGE == 4
+#define ZH_STG_H0 ZH_STG_B
+#define ZH_STG_H1 ""
+#define ZH_STG_H2 ZH_STG_ACC
+#define ZH_STG_H3 ZH_STG_A
+#else
+#define ZH_STG_H0 ""
+#define ZH_STG_H1 ""
+#define ZH_STG_H2 ""
+#define ZH_STG_H3 ""
+#endif
 #define ZH_FAST_SPIN_IN "s_memtime s[96:97]\n\t"
 #define ZH_FAST_SPIN_OK(S) ".Lzh_okp" #S "_%=:\n\ts_memtime s[98:99]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 s98, s98, s96\n\ts_subb_u32 s99, s99, s97\n\ts_add_u32 s100, s100, s98\n\ts_addc_u32 s101, s101, s99\n\ts_add_u32 %[nspin], %[nspin], 1\n\ts_branch .Lzh_ok" #S "_%=\n\t"
+#if ZH_L1_STAGE
+#define ZH_PROF_SPIN_IN ""
+#define ZH_PROF_SPIN_OKL ZH_FAST_OK_DIRECT
+#define ZH_PROF_SPIN_OKB(S) ""
+#else
+#define ZH_PROF_SPIN_IN ZH_FAST_SPIN_IN
+#define ZH_PROF_SPIN_OKL ZH_FAST_OK_STAMPED
+#define ZH_PROF_SPIN_OKB(S) ZH_FAST_SPIN_OK(S)
+#endif
 #define ZH_CM_FAST_LOOP_PROF(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_, thr_, nm_, mqa_, kb_, spin_lo_, spin_hi_, nspin_) \
   asm volatile(                                                       \
   "v_mov_b32_e32 v249, 0\n\t"                                         \
   "s_mov_b32 s100, 0\n\t"                                             \
   "s_mov_b32 s101, 0\n\t"                                             \
+  "s_memtime s[96:97]\n\t"                                            \
+  "s_waitcnt lgkmcnt(0)\n\t"                                          \
+  "s_mov_b32 s98, s96\n\t"                                            \
+  "s_mov_b32 s99, s97\n\t"                                            \
   "s_branch .Lzh_byte_%=\n\t"                                         \
   ".p2align 8\n"                                                      \
   ".Lzh_byte_%=:\n\t"                                                 \
-  ZH_CM_FAST_BYTE(a, 0, 1, 2, 3, 4, 5, 6, 7, 8)                       \
-  ZH_CM_FAST_BYTE(b, 10, 11, 12, 13, 14, 15, 16, 17, 18)              \
+  ZH_CM_FAST_BYTE(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, ZH_STG_H0, ZH_STG_H1, ZH_STG_H2, ZH_STG_H3)       \
+  ZH_CM_FAST_BYTE(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, ZH_STG_H0, ZH_STG_H1, ZH_STG_H2, ZH_STG_H3) \
   "s_branch .Lzh_byte_%=\n"                                           \
-  ZH_CM_FAST_COLD(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, ZH_FAST_SPIN_IN, ZH_FAST_OK_STAMPED)              \
-  ZH_CM_FAST_COLD(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, ZH_FAST_SPIN_IN, ZH_FAST_OK_STAMPED)     \
-  ZH_FAST_SPIN_OK(a)                                                  \
-  ZH_FAST_SPIN_OK(b)                                                  \
+  ZH_CM_FAST_COLD(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, ZH_PROF_SPIN_IN, ZH_PROF_SPIN_OKL)              \
+  ZH_CM_FAST_COLD(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, ZH_PROF_SPIN_IN, ZH_PROF_SPIN_OKL)     \
+  ZH_PROF_SPIN_OKB(a)                                                 \
+  ZH_PROF_SPIN_OKB(b)                                                 \
   /* ---- window miss, served without leaving the loop (round 4: the stage table of a miss, profiles/r04/stages_l1_miss_before.txt, \
      showed ~1 000 of its ~3 000 cycles between leaving this loop and re-entering it, and most of the rest waiting for wave B to \
      finish the byte before).  Victim = the first slot not used since message `thr` (empty slots carry 0, lanes that stand for no \
