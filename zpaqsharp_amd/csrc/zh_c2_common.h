@@ -372,7 +372,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
         }
       }
 #ifdef C2_TOUCH
-      if (C2_TOUCH && SP::id == 3 && !LDS::kMixLds) {      // (max only: +1 %; mid +0.6 % for 3.5 TB more reads per GiB — not there)
+      if (C2_TOUCH && SP::nmix > 0 && !LDS::kMixLds) {
         // lines 0-3 of the block of mixer rows each candidate byte leads to (rows 1-15: what bits 0-3 of the next byte
         // read); the rest of the winner's block is touched at the commit below.  The values are dropped, late.
         uint32_t hq = 0;
@@ -453,7 +453,7 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       if (cwn && lane == 0) S.mreg[cwi] = (uint8_t)cwv;
       if (lane < NH) { const uint32_t hv_ = S.hspec[lane][lo]; S.hreg[lane] = hv_; }
 #ifdef C2_TOUCH
-      if (C2_TOUCH && SP::id == 3 && !LDS::kMixLds) {      // (max only: +1 %; mid +0.6 % for 3.5 TB more reads per GiB — not there)
+      if (C2_TOUCH && SP::nmix > 0 && !LDS::kMixLds) {
         // the byte is known, so is the block of 255 mixer rows the next byte walks (a new 128-byte line with almost every
         // bit): one dword per line and lane now, and the decoder wave's one-bit-ahead requests find the lines in L2
         const uint32_t hq = S.hspec[SP::mix_lane[0] & (NH - 1u)][lo];

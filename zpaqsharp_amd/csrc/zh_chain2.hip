@@ -38,7 +38,8 @@ using namespace zhdev;
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 
 // Build-time variants for same-box A/B runs (tools/ab_bench.sh, tools/build_variants.sh): -DC2V=<mask>.  The shipped build is
-// everything but 16 (measured slower); 8 and 32 for the max model only (profiles/r04/ab_notes.txt): 1007.
+// everything but 8 (mid +0.6 %, max +1 % — for 3.5 TB / 21 TB more HBM reads per GiB: bytes that buy that little are not spent)
+// and 16 (measured slower); 32 for the max model only (profiles/r04/ab_notes.txt): 999.
 //   1  the decoder step hands y to the vector side itself (select mask, ey, y made under the split's SCC: ZH_DEC_STEP_Y)
 //   2  what a bit trains but the NEXT bit cannot read — mixer weights (their row changes with every bit), max's SSE entries
 //      and `mix2 8` weight — is computed one bit later, in the shadow of that bit's squash look-up (an s_load or ds_read
@@ -67,7 +68,7 @@ using namespace zhdev;
 //      checks the word afterwards (the helper is ready ~550 cycles early, round-4 stamps): one LDS round trip where round 3
 //      had three in a row (wait for ready, then h[], then the rows)
 #ifndef C2V
-#define C2V 1007
+#define C2V 999
 #endif
 #define C2_TOUCH ((C2V & 8) != 0)
 #define C2_FINDB ((C2V & 256) != 0)
