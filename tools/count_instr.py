@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction counts of the decode kernels' hot loops, from the gfx950 code objects inside libzpaqhip.so.
 
-  python tools/count_instr.py [--out profiles/r03]      (needs no GPU: llvm-objdump on the built library)
+  python tools/count_instr.py [--out profiles/<round>]      (needs no GPU: llvm-objdump on the built library)
 
 For every decode kernel: the code objects are taken out of the library (llvm-objdump --offloading), disassembled
 (llvm-objdump -d), and the BYTE LOOP is located as the innermost loop (a backward branch and its target) that contains the
@@ -93,11 +93,12 @@ def byte_loop(ins, nsteps=9):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=os.path.join(ROOT, "zpaqsharp_amd", "libzpaqhip.so"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03"))
+    ap.add_argument("--out", default=None, help="directory for instr_<kernel>.json (nothing is written without it)")
     a = ap.parse_args()
     import bench
     funcs = disassemble(a.lib)
-    os.makedirs(a.out, exist_ok=True)
+    if a.out:
+        os.makedirs(a.out, exist_ok=True)
     for tag, (sym, nsteps, nbytes) in KERNELS.items():
         ins = funcs.get(sym)
         if not ins:
@@ -120,8 +121,9 @@ def main():
         rec = {"kernel": sym, "model": tag, "src_hash": bench.source_hash(tag), "instr_per_byte_static": len(body) // nbytes, "bytes_per_loop_pass": nbytes,
                "instr_between_decoder_steps": per_step, "loop_bytes": ins[hi][0] - ins[lo][0], "mix": kinds,
                "how": f"tools/count_instr.py: innermost loop around the {nsteps} s_mul_hi_u32 decoder steps of a byte, layout order, s_nop excluded"}
-        with open(os.path.join(a.out, f"instr_{sym}.json"), "w") as f:
-            json.dump(rec, f, indent=1)
+        if a.out:
+            with open(os.path.join(a.out, f"instr_{sym}.json"), "w") as f:
+                json.dump(rec, f, indent=1)
         print(f"{sym}: {len(body) // nbytes} instructions per byte (static), between decoder steps {per_step}, {kinds}")
 
 
