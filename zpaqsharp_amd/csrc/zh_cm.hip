@@ -123,17 +123,7 @@ __device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(u
 // Where the probability of second-nibble entry (group 16 + q, position P) is kept inside p16B[slot][]:
 // quad q & 3, position, element q >> 2 — so that the four candidates of a lane of wave A (groups
 // q, q+4, q+8, q+12, same position) are adjacent: one ds_read_b64.
-#ifndef ZH_L1_PF
-#define ZH_L1_PF 0   /* measured: -12 % (profiles/r04/ab_notes.txt, call 14) */
-#endif
-#if ZH_L1_PF
-// (round 4, zh_cm_fast.h ZH_FAST_STEP_PF) the two children of a tree node are one dword — node P of group q sits in half
-// P & 1 of dword q & 1 of the 8 bytes of lane (q >> 1) * 8 + (P >> 1): one ds_read_b64 per lane fetches every pair of the
-// 16 groups, and lane (q >> 1) * 8 + j of the group's dword holds BOTH candidates of the bit after node j.
-__device__ __forceinline__ uint32_t p16b_pos(uint32_t q, uint32_t P) { return ((((q >> 1) << 3) | (P >> 1)) << 2) | ((q & 1) << 1) | (P & 1); }
-#else
 __device__ __forceinline__ uint32_t p16b_pos(uint32_t q, uint32_t P) { return ((q & 3) << 6) | (P << 2) | (q >> 2); }
-#endif
 __device__ __forceinline__ uint32_t ring_tag(uint32_t u) { return u & 127u; }   // differs between the messages u, u + 16, ... u + 112 that share a ring entry
 static_assert(kRing == 16, "ring_tag");
 // single-wave replacement of __syncthreads(): wave A must never wait on a workgroup barrier (wave B idles in a mailbox loop)
@@ -416,12 +406,7 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
   const uint32_t lsh_vis = 4 - ltt, lsh_y = 3 - ltt;
   // LDS offsets of what this lane reads per byte: probability of first-nibble node l15 (+ slot * 32) and the
   // four second-nibble candidates of quad lgrp (+ slot * 512)
-#if ZH_L1_PF
-  // ... the pair (node 2j, node 2j + 1) of first-nibble node j = lane & 7, and the two pair dwords of this lane (p16b_pos)
-  const uint32_t p_la = lds_off(&S.p16A[0][0]) + (lane & 7) * 4, p_lb = lds_off(&S.p16B[0][0]) + lane * 8;
-#else
   const uint32_t p_la = lds_off(&S.p16A[0][0]) + l15 * 2, p_lb = lds_off(&S.p16B[0][0]) + lgrp * 128 + l15 * 8;
-#endif
   const uint32_t ring_addr = lds_off(&S.ring[0]), bseq_addr = lds_off(&S.b_seq), mreq_addr = lds_off(&S.mreq);   // (mold, mdone follow mreq)
   const uint32_t dummy_addr = lds_off(&S.dummy[lane]), ring_step = lane == 0 ? 63u : 0u;   // see ZH_FAST_EPILOGUE
 
@@ -740,20 +725,12 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
               if (UNLIKELY(t - b_done > back)) { if (!wait_done(t - back)) helper_lost = 1; }
             }
             ZH_STAMP(1);
-#if ZH_L1_PF
-            const uint32_t pa = *(lds_u32_p)(p_la + slot * 32);     // lane j: nodes 2j (low half), 2j + 1 (high half)
-#else
             const uint32_t pa = (uint32_t)lds_u16(p_la + slot * 32) << 16;
-#endif
             const uint64_t pb = lds_u64(p_lb + slot * 512);
             uint32_t j = 1;
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
-#if ZH_L1_PF
-              const uint32_t ps = (rdlane(pa, j >> 1) >> ((j & 1) * 16)) << 16;
-#else
               const uint32_t ps = rdlane(pa, j);
-#endif
               uint32_t xr;
               ZH_DEC_STEP_LITE(d, ps, j, xr);
               if (UNLIKELY(xr < 0x1000000u)) {
@@ -762,21 +739,12 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
               }
             }
             // second nibble: group 16 + n1 = quad (n1 & 3), element n1 >> 2
-#if ZH_L1_PF
-            const uint32_t ga = uni(j & 15), lb = (ga >> 1) * 8;
-            const uint32_t psel = (uint32_t)(pb >> ((ga & 1) * 32));
-#else
             const uint32_t ga = uni(j & 15), lb = (ga & 3) * 16;
             const uint32_t psel = (uint32_t)(pb >> ((ga >> 2) * 16)) << 16;
-#endif
             uint32_t j2 = 1;
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
-#if ZH_L1_PF
-              const uint32_t ps = (rdlane(psel, lb + (j2 >> 1)) >> ((j2 & 1) * 16)) << 16;
-#else
               const uint32_t ps = rdlane(psel, lb + j2);
-#endif
               uint32_t xr;
               ZH_DEC_STEP_LITE(d, ps, j2, xr);
               if (UNLIKELY(xr < 0x1000000u)) {

@@ -21,25 +21,16 @@
 // as the reference words it), and xor + compare + branch for the renormalisation, which is out of line.
 //
 // Register use: operands are allocated by the compiler; temporaries are the fixed registers
-// s80-s94 and v250-v252 (declared as clobbers).  exec is all ones on entry and exit.
+// s76-s77, s80-s94 and v242-v245, v249-v252 (declared as clobbers).  exec is all ones on entry and exit.
 #pragma once
 
 // clang-format off
-#define ZH_FAST_STEP(PV, J, IDX, N) ZH_FAST_STEP_(PV, IDX, N, "s_addc_u32 " J ", " J ", " J, "")
-#define ZH_FAST_STEP1(PV, J, IDX, N) ZH_FAST_STEP_(PV, IDX, N, "s_addc_u32 " J ", 1, 1", "")   /* first step of a nibble: node 1 */
-// ... with up to four VALU instructions in the v_readlane's shadow: the first SALU instruction behind a VALU instruction that
-// writes an SGPR issues ~21 cycles after it whatever it reads, and VALU instructions in between are free
-// (tools/ubench/sgprw_bench, profiles/r04/ubench_sgprw.txt)
-#define ZH_FAST_STEP_SH(PV, J, IDX, N, SHADOW) ZH_FAST_STEP_(PV, IDX, N, "s_addc_u32 " J ", " J ", " J, SHADOW)
-// The renormalisation test for the split of bit N-1 (or the EOS flag's low + 1) sits at the START of step N, behind
-// the v_readlane of step N's probability: the three scalar instructions cover most of the VALU -> SALU hand-over that the
-// multiply would otherwise wait out (tools/ubench/step_bench: ~24 cycles).  Nothing between a split and this test reads
-// low / high / curr, so it is the reference's order of events (Decoder.cs:148-156 runs right after the split).
-// (Testing high - low < 2^24 instead — one instruction less, the step needs the range anyway — was measured and lost 6 %:
-// ranges below 2^24 whose top bytes differ are common, and each sends the wave out of line for nothing.)
-// (Measured on the same GPU box and not kept: the renormalisation test of bit N-1 moved behind step N's v_readlane —
-// 554 against 565 MB/s; the test replaced by `high - low < 2^24`, which the step computes anyway — 531 MB/s: ranges
-// below 2^24 whose top bytes differ are common, and each one sends the wave out of line for nothing.)
+// One bit: the probability of tree node IDX comes out of lane IDX of PV, SHADOW is vector work that rides in the v_readlane's
+// shadow (see below), then the split and the renormalisation test of THIS split (Decoder.cs:148-156 runs right after the
+// split: nothing between the two reads low / high / curr).
+// (Measured on one GPU box and not kept, round 3: the test moved behind the next step's v_readlane — 554 against 565 MB/s;
+// the test replaced by `high - low < 2^24`, which the step computes anyway — 531 MB/s: ranges below 2^24 whose top bytes
+// differ are common, and each one sends the wave out of line for nothing.)
 #define ZH_FAST_STEP_(PV, IDX, N, ADDC, SHADOW)                       \
   "v_readlane_b32 s94, " PV ", " IDX "\n\t"                           \
   SHADOW                                                              \
@@ -59,50 +50,6 @@
 // v_readlane that takes it as its lane select (a lane select the SALU has only just written costs the v_readlane extra)
 #define ZH_FAST_ADDC_IDX(J) "s_addc_u32 " J ", " J ", " J "\n\ts_add_u32 s80, s89, " J
 #define ZH_FAST_ADDC1_IDX(J) "s_addc_u32 " J ", 1, 1\n\ts_add_u32 s80, s89, " J
-
-// (round 4) The step with the NEXT bit's probability fetched both ways: lane IDX of PLO / PHI holds the two children of the
-// node this step decides (node 2j for y = 0 shifted into the high half, node 2j + 1 for y = 1 in place: p16b_pos in
-// zh_cm.hip), both are read while the split is being computed and the bit picks one with an s_cselect.  The step's own
-// probability is in s94 when it starts, so the chain  s_addc j -> v_readlane p[j] -> s_mul_hi  (a SALU -> VALU -> SALU round
-// trip per bit, ~30 cycles of stall: tools/ubench/step_bench) becomes  s_cselect -> s_mul_hi;  two instructions more per bit.
-// MEASURED AND NOT THE DEFAULT (-DZH_L1_PF=1 builds it): 522 against 595 MB/s on one box.  The ~30 cycles behind a v_readlane
-// stayed although no instruction near it reads the SGPR any more: the first SALU instruction that follows a VALU instruction
-// writing an SGPR waits for that write whatever it reads, so the cost is per v_readlane, not per dependency.
-#define ZH_FAST_STEP_PF_(PLO, PHI, IDX, N, ADDC, EXTRA)               \
-  "s_sub_u32 s84, %[high], %[low]\n\t"                                \
-  "s_mul_hi_u32 s86, s84, s94\n\t"                                    \
-  "v_readlane_b32 s85, " PLO ", " IDX "\n\t"                          \
-  "v_readlane_b32 s93, " PHI ", " IDX "\n\t"                          \
-  "s_add_u32 s87, %[low], s86\n\t"                                    \
-  "s_add_u32 s88, s87, 1\n\t"                                         \
-  "s_cmp_le_u32 %[curr], s87\n\t"                                     \
-  "s_cselect_b32 %[high], s87, %[high]\n\t"                           \
-  "s_cselect_b32 %[low], %[low], s88\n\t"                             \
-  "s_cselect_b32 s94, s93, s85\n\t"                                   \
-  EXTRA                                                               \
-  ADDC "\n\t"                                                         \
-  "s_xor_b32 s84, %[high], %[low]\n\t"                                \
-  "s_cmp_lt_u32 s84, 0x1000000\n\t"                                   \
-  "s_cbranch_scc1 .Lzh_rn" #N "_%=\n"                                 \
-  ".Lzh_bk" #N "_%=:\n\t"
-#define ZH_FAST_STEP_PF(PLO, PHI, J, IDX, N) ZH_FAST_STEP_PF_(PLO, PHI, IDX, N, "s_addc_u32 " J ", " J ", " J, "")
-#define ZH_FAST_STEP_PF1(PLO, PHI, J, IDX, N) ZH_FAST_STEP_PF_(PLO, PHI, IDX, N, "s_addc_u32 " J ", 1, 1", "")
-// ... last step of the first nibble: the candidates are the roots of groups 2 (j & 7) and 2 (j & 7) + 1; s[78:79] = y, for the dword select
-#define ZH_FAST_STEP_PF4(PLO, PHI, J, IDX, N) ZH_FAST_STEP_PF_(PLO, PHI, IDX, N, "s_addc_u32 " J ", " J ", " J, "s_cselect_b64 s[78:79], -1, 0\n\t")
-// ... the byte's last step: nothing to fetch
-#define ZH_FAST_STEP_LAST(J, N)                                       \
-  "s_sub_u32 s84, %[high], %[low]\n\t"                                \
-  "s_mul_hi_u32 s86, s84, s94\n\t"                                    \
-  "s_add_u32 s87, %[low], s86\n\t"                                    \
-  "s_add_u32 s88, s87, 1\n\t"                                         \
-  "s_cmp_le_u32 %[curr], s87\n\t"                                     \
-  "s_cselect_b32 %[high], s87, %[high]\n\t"                           \
-  "s_cselect_b32 %[low], %[low], s88\n\t"                             \
-  "s_addc_u32 " J ", " J ", " J "\n\t"                                \
-  "s_xor_b32 s84, %[high], %[low]\n\t"                                \
-  "s_cmp_lt_u32 s84, 0x1000000\n\t"                                   \
-  "s_cbranch_scc1 .Lzh_rn" #N "_%=\n"                                 \
-  ".Lzh_bk" #N "_%=:\n\t"
 
 // Renormalisation (Decoder.cs:148-156): shift a coded byte in while the top bytes of low and
 // high agree; then the range test the next decode() would make (after the byte's last bit: ZH_FAST_CHK8).
@@ -154,24 +101,34 @@
 // of message t (the other lanes of `vr` hold the addresses of their own dummy words: no exec switch around the write);
 // then the ring address of lane 0 steps on (v_bfi keeps the other lanes), t, the slot's last-use stamp (vcc still is
 // the one-hot lane mask of the window lookup: nothing in the loop writes vcc after it), h[0]
-#ifndef ZH_L1_SH2
-#define ZH_L1_SH2 1
-#endif
-#if ZH_L1_SH2
-// (round 4) Everything of a byte's bookkeeping that is vector work or can be made vector work sits in the shadow of a
-// v_readlane (the first SALU instruction behind a VALU instruction that writes an SGPR issues ~21 cycles after it, whatever it
-// reads; up to three or four VALU instructions in between are free: tools/ubench/sgprw_bench, profiles/r04/ubench_sgprw.txt):
-//   step 2: the window's last-use stamp t + 1;   step 3: v242 = max(last use, t + 1 - 13), the NEXT byte's lag test as one
-//   compare (wave B may be at most min(messages since the window's last use, 13) behind:  t - bdone <= min(t - lu, 13)  <=>
-//   max(lu, t - 13) <= bdone; signed, t - 13 is negative at first);   steps 6, 7: the message without the byte,
-//   tag(t) << 25 | slot;   step 8: the next ring address (v251 is free since the nibble switch).
-// The epilogue then is the byte, one v_lshl_or for the message, the write, and t, h[0].
+// (round 4) Everything of a byte's bookkeeping that is vector work, or can be made vector work, sits in the SHADOW of a
+// v_readlane: the first SALU instruction behind a VALU instruction that writes an SGPR issues ~21 cycles after it whatever it
+// reads, and up to three or four VALU instructions in between are free (tools/ubench/sgprw_bench,
+// profiles/r04/ubench_sgprw.txt; same-box A/Bs of every step: profiles/r04/ab_notes.txt, calls 14-19):
+//   step 1: wave B's progress counter, read from LDS with the byte's probabilities, is taken over (a second SGPR-writing
+//           VALU instruction back to back costs one issue slot, not a second stall): the NEXT byte's lag test works on a
+//           counter one byte old instead of one that is only refreshed after a failed test;
+//   step 2: the window's last-use stamp t + 1 (vcc still is the one-hot lane mask of the window lookup: nothing in the loop
+//           writes vcc after it);
+//   step 3: v242 = max(last use, t + 1 - 13) — the next byte's lag test as ONE compare: wave B may be at most
+//           min(messages since the window's last use, 13) behind,  t - bdone <= min(t - lu, 13)  <=>  max(lu, t - 13) <= bdone
+//           (signed: t - 13 is negative at first; lanes that stand for no slot carry -1 and are masked by the lookup);
+//   steps 6, 7: the message without the byte, tag(t) << 25 | slot;
+//   step 8: the next ring address of lane 0 (v_bfi keeps the other lanes, which point at dummy words: no exec switch around
+//           the write; v251 is free since the nibble switch).
+// The epilogue then is: byte = (j << 4) + j2 - 272, message = byte << 15 | (tag | slot) by one v_lshl_or, the write, t, h[0].
+// Measured and not kept: the step with the next bit's probability fetched both ways (pairs of children per lane, two v_readlane
+// while the split is computed, one s_cselect by the bit: the chain s_addc -> v_readlane -> s_mul_hi becomes s_cselect ->
+// s_mul_hi) — 522 against 595 MB/s: the ~21 cycles behind a v_readlane are not a dependency a schedule can cover.
+#define ZH_FAST_READ_BSEQ "ds_read_b32 v245, %[bsa]\n\t"
+#define ZH_FAST_SHADOW1 "v_readfirstlane_b32 %[bdone], v245\n\t"
 #define ZH_FAST_SHADOW2 "v_add_u32_e64 v252, %[t], 1\n\tv_cndmask_b32_e32 %[lu], %[lu], v252, vcc\n\t"
 #define ZH_FAST_SHADOW3 "v_add_u32_e64 v244, %[t], -12\n\tv_max_i32_e32 v242, v244, %[lu]\n\t"
 #define ZH_FAST_SHADOW6 "v_mov_b32_e32 v243, s82\n\t"
 #define ZH_FAST_SHADOW7 "v_lshl_or_b32 v243, %[t], 25, v243\n\t"
 #define ZH_FAST_SHADOW8 "v_add_u32_e32 v251, 4, %[vr]\n\tv_bfi_b32 v251, %[vm], v251, %[vr]\n\t"
-#define ZH_FAST_LAGV "v_add_u32_e64 v244, %[t], -13\n\tv_max_i32_e32 v242, v244, %[lu]\n\t"   /* v242 for THIS byte: loop entry, and after a miss has re-stamped a slot */
+// v242 for THIS byte: at loop entry, and after a miss has re-stamped a slot
+#define ZH_FAST_LAGV "v_add_u32_e64 v244, %[t], -13\n\tv_max_i32_e32 v242, v244, %[lu]\n\t"
 #define ZH_FAST_EPILOGUE                                              \
   "s_lshl4_add_u32 s92, s90, s91\n\t"                                 \
   "s_add_u32 s92, s92, 0xfffffef0\n\t"                                \
@@ -180,6 +137,8 @@
   "v_mov_b32_e32 %[vr], v251\n\t"                                     \
   "s_add_u32 %[t], %[t], 1\n\t"                                       \
   "s_lshl_b32 %[h0], s92, %[hs]\n\t"
+// window lookup (lane s of `tag` holds the window id cached in slot s) and lag test; the out-of-line wait computes the
+// allowance min(t - lu[slot], 13) itself
 #define ZH_FAST_LOOKUP(S)                                             \
   "s_bfe_u32 s81, %[h0], %[bfe]\n\t"                                  \
   "v_cmp_eq_u32_e32 vcc, s81, %[tag]\n\t"                             \
@@ -189,75 +148,13 @@
   "s_and_b64 s[76:77], s[76:77], vcc\n\t"                             \
   "s_cbranch_scc1 .Lzh_fresh" #S "_%=\n"
 #define ZH_FAST_FRESH_IN "v_readlane_b32 s83, %[lu], s82\n\ts_sub_u32 s83, %[t], s83\n\ts_min_u32 s83, s83, 13\n\t"
-#define ZH_FAST_CLOBBER_LAG , "s76", "s77", "v242", "v243", "v244"
-#else
-#define ZH_FAST_SHADOW2 ""
-#define ZH_FAST_SHADOW3 ""
-#define ZH_FAST_SHADOW6 ""
-#define ZH_FAST_SHADOW7 ""
-#define ZH_FAST_LAGV ""
-#ifndef ZH_L1_EPI2
-#define ZH_L1_EPI2 1
-#endif
-#if ZH_L1_EPI2
-// (round 4) what of the epilogue does not need the byte — the next ring address (into v251, free since the nibble switch) and
-// the window's last-use stamp t + 1 — sits in the shadow of the last step's v_readlane (ZH_FAST_STEP_SH)
-#define ZH_FAST_SHADOW8                                               \
-  "v_add_u32_e64 v252, %[t], 1\n\t"                                   \
-  "v_add_u32_e32 v251, 4, %[vr]\n\t"                                  \
-  "v_cndmask_b32_e32 %[lu], %[lu], v252, vcc\n\t"                     \
-  "v_bfi_b32 v251, %[vm], v251, %[vr]\n\t"
-#define ZH_FAST_EPILOGUE                                              \
-  "s_lshl4_add_u32 s92, s90, s91\n\t"                                 \
-  "s_add_u32 s92, s92, 0xfffffef0\n\t"                                \
-  "s_lshl_b32 s80, %[t], 25\n\t"                                      \
-  "s_lshl_b32 s84, s92, 15\n\t"                                       \
-  "s_or_b32 s80, s80, s84\n\t"                                        \
-  "s_or_b32 s80, s80, s82\n\t"                                        \
-  "v_mov_b32_e32 v250, s80\n\t"                                       \
-  "ds_write_b32 %[vr], v250\n\t"                                      \
-  "v_mov_b32_e32 %[vr], v251\n\t"                                     \
-  "s_add_u32 %[t], %[t], 1\n\t"                                       \
-  "s_lshl_b32 %[h0], s92, %[hs]\n\t"
-#else
-#define ZH_FAST_SHADOW8 ""
-#define ZH_FAST_EPILOGUE                                              \
-  "s_lshl4_add_u32 s92, s90, s91\n\t"                                 \
-  "s_add_u32 s92, s92, 0xfffffef0\n\t"                                \
-  "s_lshl_b32 s80, %[t], 25\n\t"                                      \
-  "s_lshl_b32 s84, s92, 15\n\t"                                       \
-  "s_or_b32 s80, s80, s84\n\t"                                        \
-  "s_or_b32 s80, s80, s82\n\t"                                        \
-  "v_mov_b32_e32 v250, s80\n\t"                                       \
-  "ds_write_b32 %[vr], v250\n\t"                                      \
-  "v_add_u32_e32 v252, 4, %[vr]\n\t"                                  \
-  "v_bfi_b32 %[vr], %[vm], v252, %[vr]\n\t"                           \
-  "s_add_u32 %[t], %[t], 1\n\t"                                       \
-  "v_mov_b32_e32 v252, %[t]\n\t"                                      \
-  "v_cndmask_b32_e32 %[lu], %[lu], v252, vcc\n\t"                     \
-  "s_lshl_b32 %[h0], s92, %[hs]\n\t"
-#endif
-#endif   /* ZH_L1_SH2 */
-
-#ifndef ZH_L1_BSEQ
-#define ZH_L1_BSEQ 1
-#endif
-#if ZH_L1_BSEQ
-// (round 4) wave B's progress counter is read with every byte's probabilities and taken over in the shadow of the first
-// step's v_readlane (a second SGPR-writing VALU instruction back to back costs one issue slot, not a second SALU stall): the
-// lag test of the NEXT byte then works on a counter one byte old instead of one that is only refreshed after a failed test.
-#define ZH_FAST_READ_BSEQ "ds_read_b32 v245, %[bsa]\n\t"
-#define ZH_FAST_SHADOW1 "v_readfirstlane_b32 %[bdone], v245\n\t"
-#else
-#define ZH_FAST_READ_BSEQ ""
-#define ZH_FAST_SHADOW1 ""
-#endif
-#ifndef ZH_L1_IDX2
-#define ZH_L1_IDX2 1
-#endif
-// second nibble: group n1 = quad (n1 & 3), element n1 >> 2
-#if ZH_L1_IDX2
-#define ZH_FAST_NIB2(N5, N6, N7, N8)                                  \
+// the eight bit steps: first nibble, node j in lane j of v249 (high half); second nibble, group n1 = quad (n1 & 3), element
+// n1 >> 2 of the four candidates a lane holds in v[250:251]
+#define ZH_FAST_BITS(N1, N2, N3, N4, N5, N6, N7, N8)                  \
+  ZH_FAST_STEP_("v249", "1", N1, "s_addc_u32 s90, 1, 1", ZH_FAST_SHADOW1)\
+  ZH_FAST_STEP_("v249", "s90", N2, "s_addc_u32 s90, s90, s90", ZH_FAST_SHADOW2)\
+  ZH_FAST_STEP_("v249", "s90", N3, "s_addc_u32 s90, s90, s90", ZH_FAST_SHADOW3)\
+  ZH_FAST_STEP_("v249", "s90", N4, "s_addc_u32 s90, s90, s90", "")    \
   "s_and_b32 s89, s90, 3\n\t"                                         \
   "s_lshl_b32 s89, s89, 4\n\t"                                        \
   "s_lshl_b32 s83, s90, 2\n\t"                                        \
@@ -268,111 +165,12 @@
   ZH_FAST_STEP_("v250", "s80", N5, ZH_FAST_ADDC1_IDX("s91"), "")      \
   ZH_FAST_STEP_("v250", "s80", N6, ZH_FAST_ADDC_IDX("s91"), ZH_FAST_SHADOW6)\
   ZH_FAST_STEP_("v250", "s80", N7, ZH_FAST_ADDC_IDX("s91"), ZH_FAST_SHADOW7)\
-  ZH_FAST_STEP_SH("v250", "s91", "s80", N8, ZH_FAST_SHADOW8)
-#else
-#define ZH_FAST_NIB2(N5, N6, N7, N8)                                  \
-  "s_lshl_b32 s80, s90, 2\n\t"                                        \
-  "s_and_b32 s80, s80, 48\n\t"                                        \
-  "s_and_b32 s89, s90, 3\n\t"                                         \
-  "s_lshl_b32 s89, s89, 4\n\t"                                        \
-  "v_lshrrev_b64 v[250:251], s80, v[250:251]\n\t"                     \
-  "v_lshlrev_b32_e32 v250, 16, v250\n\t"                              \
-  "s_add_u32 s80, s89, 1\n\t"                                         \
-  ZH_FAST_STEP1("v250", "s91", "s80", N5)                             \
-  "s_add_u32 s80, s89, s91\n\t"                                       \
-  ZH_FAST_STEP_SH("v250", "s91", "s80", N6, ZH_FAST_SHADOW6)          \
-  "s_add_u32 s80, s89, s91\n\t"                                       \
-  ZH_FAST_STEP_SH("v250", "s91", "s80", N7, ZH_FAST_SHADOW7)          \
-  "s_add_u32 s80, s89, s91\n\t"                                       \
-  ZH_FAST_STEP_SH("v250", "s91", "s80", N8, ZH_FAST_SHADOW8)
-#endif
-#ifndef ZH_L1_PF
-#define ZH_L1_PF 0   /* measured: -12 % (profiles/r04/ab_notes.txt, call 14) */
-#endif
-#if ZH_L1_PF
-#define ZH_FAST_READ_A "ds_read_b32 v249, v252\n\t"
-// v249 / v248: first-nibble pairs, high halves in place / low halves shifted up;  v247 / v246: high halves of dword 0 / 1 of the
-// second-nibble pairs (lane (g >> 1) * 8 holds the root of group g there);  after the first nibble v250 / v251: the chosen
-// group's pairs, high halves in place / low halves shifted up;  s89: the group's first lane
-#define ZH_FAST_BITS(N1, N2, N3, N4, N5, N6, N7, N8)                  \
-  "v_lshlrev_b32_e32 v248, 16, v249\n\t"                              \
-  "v_and_b32_e32 v249, 0xffff0000, v249\n\t"                          \
-  "v_and_b32_e32 v247, 0xffff0000, v250\n\t"                          \
-  "v_readlane_b32 s94, v249, 0\n\t"                                   \
-  "v_and_b32_e32 v246, 0xffff0000, v251\n\t"                          \
-  ZH_FAST_STEP_PF1("v248", "v249", "s90", "1", N1)                    \
-  ZH_FAST_STEP_PF("v248", "v249", "s90", "s90", N2)                   \
-  ZH_FAST_STEP_PF("v248", "v249", "s90", "s90", N3)                   \
-  "s_and_b32 s80, s90, 7\n\t"                                         \
-  "s_lshl_b32 s80, s80, 3\n\t"                                        \
-  ZH_FAST_STEP_PF4("v247", "v246", "s90", "s80", N4)                  \
-  /* second nibble: group n1 = dword n1 & 1 of lanes (n1 >> 1) * 8 .. + 7 */\
-  "v_cndmask_b32_e64 v250, v250, v251, s[78:79]\n\t"                  \
-  "s_and_b32 s89, s90, 14\n\t"                                        \
-  "s_lshl_b32 s89, s89, 2\n\t"                                        \
-  "v_lshlrev_b32_e32 v251, 16, v250\n\t"                              \
-  "v_and_b32_e32 v250, 0xffff0000, v250\n\t"                          \
-  "s_add_u32 s80, s89, 1\n\t"                                         \
-  ZH_FAST_STEP_PF1("v251", "v250", "s91", "s80", N5)                  \
-  "s_add_u32 s80, s89, s91\n\t"                                       \
-  ZH_FAST_STEP_PF("v251", "v250", "s91", "s80", N6)                   \
-  "s_add_u32 s80, s89, s91\n\t"                                       \
-  ZH_FAST_STEP_PF("v251", "v250", "s91", "s80", N7)                   \
-  ZH_FAST_STEP_LAST("s91", N8)
-#define ZH_FAST_CLOBBER_PF , "s78", "s79", "s93", "v246", "v247", "v248"
-#else
-#define ZH_FAST_READ_A "ds_read_u16_d16_hi v249, v252\n\t"
-#define ZH_FAST_BITS(N1, N2, N3, N4, N5, N6, N7, N8)                  \
-  ZH_FAST_STEP_("v249", "1", N1, "s_addc_u32 s90, 1, 1", ZH_FAST_SHADOW1) \
-  ZH_FAST_STEP_SH("v249", "s90", "s90", N2, ZH_FAST_SHADOW2)          \
-  ZH_FAST_STEP_SH("v249", "s90", "s90", N3, ZH_FAST_SHADOW3)          \
-  ZH_FAST_STEP("v249", "s90", "s90", N4)                              \
-  ZH_FAST_NIB2(N5, N6, N7, N8)
-#define ZH_FAST_CLOBBER_PF
-#endif
-#if !ZH_L1_SH2
-#ifndef ZH_L1_LAG2
-#define ZH_L1_LAG2 1
-#endif
-#if ZH_L1_LAG2
-// (round 4) Window lookup and lag test.  Wave B may be at most min(messages since the window's last use, 13) behind:
-//   t - bdone <= min(t - lu[slot], 13)   <=>   lu[slot] <= bdone  and  t - bdone <= 13,
-// and the left test is one v_cmp over the last-use VGPR ANDed with the lookup's one-hot mask — no s_ff1 -> v_readlane -> s_sub
-// chain (two SALU <-> VALU hand-overs) in front of the LDS addresses.  The out-of-line wait computes the allowance itself.
-#define ZH_FAST_LOOKUP(S)                                             \
-  "s_bfe_u32 s81, %[h0], %[bfe]\n\t"                                  \
-  "v_cmp_eq_u32_e32 vcc, s81, %[tag]\n\t"                             \
-  "v_cmp_gt_u32_e64 s[76:77], %[lu], %[bdone]\n\t"                    \
-  "s_sub_u32 s89, %[t], %[bdone]\n\t"                                 \
-  "s_cbranch_vccz .Lzh_miss_%=\n\t"                                   \
-  "s_ff1_i32_b64 s82, vcc\n\t"                                        \
-  "s_and_b64 s[76:77], s[76:77], vcc\n\t"                             \
-  "s_cbranch_scc1 .Lzh_fresh" #S "_%=\n\t"                            \
-  "s_cmp_gt_u32 s89, 13\n\t"                                          \
-  "s_cbranch_scc1 .Lzh_fresh" #S "_%=\n"
-#define ZH_FAST_FRESH_IN "v_readlane_b32 s83, %[lu], s82\n\ts_sub_u32 s83, %[t], s83\n\ts_min_u32 s83, s83, 13\n\t"
-#define ZH_FAST_CLOBBER_LAG , "s76", "s77"
-#else
-#define ZH_FAST_LOOKUP(S)                                             \
-  /* window lookup: lane s of `tag` holds the window id cached in slot s */ \
-  "s_bfe_u32 s81, %[h0], %[bfe]\n\t"                                  \
-  "v_cmp_eq_u32_e32 vcc, s81, %[tag]\n\t"                             \
-  "s_cbranch_vccz .Lzh_miss_%=\n\t"                                   \
-  "s_ff1_i32_b64 s82, vcc\n\t"                                        \
-  /* wave B may be at most min(messages since the window's last use, 13) behind */ \
-  "v_readlane_b32 s83, %[lu], s82\n\t"                                \
-  "s_sub_u32 s83, %[t], s83\n\t"                                      \
-  "s_min_u32 s83, s83, 13\n\t"                                        \
-  "s_sub_u32 s89, %[t], %[bdone]\n\t"                                 \
-  "s_cmp_gt_u32 s89, s83\n\t"                                         \
-  "s_cbranch_scc1 .Lzh_fresh" #S "_%=\n"
-#define ZH_FAST_FRESH_IN ""
-#define ZH_FAST_CLOBBER_LAG
-#endif
-#endif   /* !ZH_L1_SH2 */
-// s80 scratch   s81 window id   s82 slot   s83 back   s84-s88 step scratch   s89 lag
+  ZH_FAST_STEP_("v250", "s80", N8, "s_addc_u32 s91, s91, s91", ZH_FAST_SHADOW8)
+// s76:s77 lag-test mask   s80 lane of the next second-nibble step / scratch   s81 window id   s82 slot
+// s83 allowance of the out-of-line wait / shift of the nibble switch   s84-s88 step scratch   s89 first lane of the group's quad
 // s90 j (16|n1) s91 j2 (16|n2)  s92 byte   s94 probability
-// v250:v251 four second-nibble probabilities / selected one   v252 scratch
+// v242 lag-test operand   v243 message without the byte   v244 scratch   v245 wave B's counter as read from LDS
+// v250:v251 four second-nibble probabilities / selected one (v251 later: next ring address)   v252 scratch
 // v249 first-nibble probabilities << 16 (loaded into the high half: ds_read_u16_d16_hi; its low half stays zero)
 //
 // Invariant on entry and at every .Lzh_byte: low <= curr <= high unless the coder is unprimed (curr == 0 < low) — every
@@ -391,7 +189,7 @@
   /* Issued before the remaining tests so that their latency is covered; a slow exit waits for them. */ \
   "v_lshl_add_u32 v252, s82, 5, %[la]\n\t"                            \
   "v_lshl_add_u32 v250, s82, 9, %[lb]\n\t"                            \
-  ZH_FAST_READ_A                                                      \
+  "ds_read_u16_d16_hi v249, v252\n\t"                                 \
   "ds_read_b64 v[250:251], v250\n\t"                                  \
   ZH_FAST_READ_BSEQ                                                   \
   /* at least 40 coded bytes in the chunk (klim = avail - 40, or 0) */ \
@@ -518,7 +316,7 @@
   : [klim] "s"(klim_), [bfe] "s"(bfe_), [hs] "s"(hs_), [vm] "v"(vm_), [bsa] "v"(bsa_),             \
     [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [mqa] "v"(mqa_), [kb] "s"(kb_)                        \
   : "memory", "scc", "vcc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",   \
-    "s91", "s92", "s94", "v249", "v250", "v251", "v252", "v245" ZH_FAST_CLOBBER_PF ZH_FAST_CLOBBER_LAG)
+    "s91", "s92", "s94", "v249", "v250", "v251", "v252", "v245", "s76", "s77", "v242", "v243", "v244")
 // Diagnostic build (zh_decode_cm_prof): the same loop with the cycles spent in the spin (wave A waiting for wave B: a window
 // being swapped in, or B behind by more than the window's lag allowance) summed into spin_ (s96-s101 are scratch here).
 // -DZH_L1_STAGE=n (n = 1..4) turns the diagnostic loop into a STAGE build instead: the cycles between two points of the byte
@@ -652,5 +450,5 @@
   : [klim] "s"(klim_), [bfe] "s"(bfe_), [hs] "s"(hs_), [vm] "v"(vm_), [bsa] "v"(bsa_),             \
     [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [mqa] "v"(mqa_), [kb] "s"(kb_)                        \
   : "memory", "scc", "vcc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",   \
-    "s91", "s92", "s94", "s96", "s97", "s98", "s99", "s100", "s101", "v249", "v250", "v251", "v252", "v245" ZH_FAST_CLOBBER_PF ZH_FAST_CLOBBER_LAG)
+    "s91", "s92", "s94", "s96", "s97", "s98", "s99", "s100", "s101", "v249", "v250", "v251", "v252", "v245", "s76", "s77", "v242", "v243", "v244")
 // clang-format on
