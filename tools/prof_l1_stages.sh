@@ -14,10 +14,10 @@ import json, sys
 n, kind = int(sys.argv[1]), sys.argv[2]
 d = json.loads(open('/tmp/ps.json').read().strip().splitlines()[-1])
 c = [int(x) for x in [l for l in open('/tmp/ps.err') if l.startswith('ZPAQHIP_PROF cycles:')][-1].split(':')[1].split()]
-what = {1: "byte start -> lag test passed (window lookup, last-use read, lag test)",
-        2: "-> probabilities back (LDS addresses, two ds_read, chunk test, EOS flag, s_waitcnt)",
+what = {1: "byte start -> lag test passed (window lookup and lag test: two v_cmp, s_ff1, s_and_b64)",
+        2: "-> probabilities back (LDS addresses, three ds_read, chunk test, EOS flag, s_waitcnt)",
         3: "-> eight bit steps and the nibble switch",
-        4: "-> epilogue (byte, message, ring address, last-use stamp, h[0]) and loop branch, to the next byte's start"}[n]
+        4: "-> epilogue (byte, message, t, h[0]) and loop branch, to the next byte's start"}[n]
 print(f"stage {n}: {c[11] / max(1, c[3]):7.1f} cycles per byte   {what}   [{kind}, {d['value']:.0f} MB/s in this build, whole loop {c[2] / max(1, c[3]):.0f} cycles per byte, bit_exact {d['bit_exact']}]")
 PY
 done

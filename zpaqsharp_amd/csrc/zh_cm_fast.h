@@ -43,7 +43,7 @@
   "s_cselect_b32 %[low], %[low], s88\n\t"                             \
   ADDC "\n\t"                                                         \
   "s_xor_b32 s84, %[high], %[low]\n\t"                                \
-  "s_cmp_lt_u32 s84, 0x1000000\n\t"                                   \
+  "s_cmp_lt_u32 s84, %[c24]\n\t"                                      \
   "s_cbranch_scc1 .Lzh_rn" #N "_%=\n"                                 \
   ".Lzh_bk" #N "_%=:\n\t"
 // second nibble: the next step's lane (s89 + j2) is computed right behind the s_addc, three instructions ahead of the
@@ -121,17 +121,19 @@
 // while the split is computed, one s_cselect by the bit: the chain s_addc -> v_readlane -> s_mul_hi becomes s_cselect ->
 // s_mul_hi) — 522 against 595 MB/s: the ~21 cycles behind a v_readlane are not a dependency a schedule can cover.
 #define ZH_FAST_READ_BSEQ "ds_read_b32 v245, %[bsa]\n\t"
-#define ZH_FAST_SHADOW1 "v_readfirstlane_b32 %[bdone], v245\n\t"
+#define ZH_FAST_SHADOW1 "v_readfirstlane_b32 %[bdone], v245\n\tv_mov_b32_e32 v243, s82\n\tv_nop\n\t"
 #define ZH_FAST_SHADOW2 "v_add_u32_e64 v252, %[t], 1\n\tv_cndmask_b32_e32 %[lu], %[lu], v252, vcc\n\t"
 #define ZH_FAST_SHADOW3 "v_add_u32_e64 v244, %[t], -12\n\tv_max_i32_e32 v242, v244, %[lu]\n\t"
-#define ZH_FAST_SHADOW6 "v_mov_b32_e32 v243, s82\n\t"
-#define ZH_FAST_SHADOW7 "v_lshl_or_b32 v243, %[t], 25, v243\n\t"
-#define ZH_FAST_SHADOW8 "v_add_u32_e32 v251, 4, %[vr]\n\tv_bfi_b32 v251, %[vm], v251, %[vr]\n\t"
+#define ZH_FAST_SHADOW4 "v_lshl_or_b32 v243, %[t], 25, v243\n\tv_nop\n\t"
+#define ZH_FAST_SHADOW5 "v_add_u32_e32 v251, 4, %[vr]\n\tv_nop\n\t"
+#define ZH_FAST_SHADOW6 "v_bfi_b32 v251, %[vm], v251, %[vr]\n\t"
+#define ZH_FAST_SHADOW7 "v_nop\n\tv_nop\n\t"
+#define ZH_FAST_SHADOW8 "v_nop\n\tv_nop\n\tv_nop\n\t"
 // v242 for THIS byte: at loop entry, and after a miss has re-stamped a slot
 #define ZH_FAST_LAGV "v_add_u32_e64 v244, %[t], -13\n\tv_max_i32_e32 v242, v244, %[lu]\n\t"
 #define ZH_FAST_EPILOGUE                                              \
   "s_lshl4_add_u32 s92, s90, s91\n\t"                                 \
-  "s_add_u32 s92, s92, 0xfffffef0\n\t"                                \
+  "s_addk_i32 s92, 0xfef0\n\t"                                        \
   "v_lshl_or_b32 v250, s92, 15, v243\n\t"                             \
   "ds_write_b32 %[vr], v250\n\t"                                      \
   "v_mov_b32_e32 %[vr], v251\n\t"                                     \
@@ -142,7 +144,9 @@
 #define ZH_FAST_LOOKUP(S)                                             \
   "s_bfe_u32 s81, %[h0], %[bfe]\n\t"                                  \
   "v_cmp_eq_u32_e32 vcc, s81, %[tag]\n\t"                             \
+  "v_nop\n\t"                                                         \
   "v_cmp_gt_i32_e64 s[76:77], v242, %[bdone]\n\t"                     \
+  "v_nop\n\tv_nop\n\tv_nop\n\t"                                     \
   "s_cbranch_vccz .Lzh_miss_%=\n\t"                                   \
   "s_ff1_i32_b64 s82, vcc\n\t"                                        \
   "s_and_b64 s[76:77], s[76:77], vcc\n\t"                             \
@@ -154,7 +158,7 @@
   ZH_FAST_STEP_("v249", "1", N1, "s_addc_u32 s90, 1, 1", ZH_FAST_SHADOW1)\
   ZH_FAST_STEP_("v249", "s90", N2, "s_addc_u32 s90, s90, s90", ZH_FAST_SHADOW2)\
   ZH_FAST_STEP_("v249", "s90", N3, "s_addc_u32 s90, s90, s90", ZH_FAST_SHADOW3)\
-  ZH_FAST_STEP_("v249", "s90", N4, "s_addc_u32 s90, s90, s90", "")    \
+  ZH_FAST_STEP_("v249", "s90", N4, "s_addc_u32 s90, s90, s90", ZH_FAST_SHADOW4)    \
   "s_and_b32 s89, s90, 3\n\t"                                         \
   "s_lshl_b32 s89, s89, 4\n\t"                                        \
   "s_lshl_b32 s83, s90, 2\n\t"                                        \
@@ -162,7 +166,7 @@
   "s_add_u32 s80, s89, 1\n\t"                                         \
   "v_lshrrev_b64 v[250:251], s83, v[250:251]\n\t"                     \
   "v_lshlrev_b32_e32 v250, 16, v250\n\t"                              \
-  ZH_FAST_STEP_("v250", "s80", N5, ZH_FAST_ADDC1_IDX("s91"), "")      \
+  ZH_FAST_STEP_("v250", "s80", N5, ZH_FAST_ADDC1_IDX("s91"), ZH_FAST_SHADOW5)      \
   ZH_FAST_STEP_("v250", "s80", N6, ZH_FAST_ADDC_IDX("s91"), ZH_FAST_SHADOW6)\
   ZH_FAST_STEP_("v250", "s80", N7, ZH_FAST_ADDC_IDX("s91"), ZH_FAST_SHADOW7)\
   ZH_FAST_STEP_("v250", "s80", N8, "s_addc_u32 s91, s91, s91", ZH_FAST_SHADOW8)
@@ -200,7 +204,7 @@
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
   "s_add_u32 %[low], %[low], 1\n\t"                                   \
   "s_xor_b32 s84, %[high], %[low]\n\t"                                \
-  "s_cmp_lt_u32 s84, 0x1000000\n\t"                                   \
+  "s_cmp_lt_u32 s84, %[c24]\n\t"                                      \
   "s_cbranch_scc1 .Lzh_rn" #E "_%=\n"                                 \
   ".Lzh_bk" #E "_%=:\n\t"                                             \
   "s_waitcnt lgkmcnt(0)\n\t"                                          \
@@ -242,12 +246,21 @@
   ZH_FAST_EPILOGUE                                                    \
   "s_branch .Lzh_slow_%=\n"
 
+// Where the loop lies against its 256-byte alignment (dwords of padding behind the .p2align, jumped over at entry):
+// -DZH_L1_PAD=n shifts the unchanged body by 4n bytes (profiles/r04/ab_notes.txt, call 22)
+#ifndef ZH_L1_PAD
+#define ZH_L1_PAD 5
+#endif
+#define ZH_STR_(x) #x
+#define ZH_STR(x) ZH_STR_(x)
+#define ZH_FAST_PAD ".fill " ZH_STR(ZH_L1_PAD) ", 4, 0xbf800000\n"
 #define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_, thr_, nm_, mqa_, kb_) \
   asm volatile(                                                       \
   "v_mov_b32_e32 v249, 0\n\t"                                         \
   ZH_FAST_LAGV                                                        \
   "s_branch .Lzh_byte_%=\n\t"   /* over the alignment padding: up to 63 s_nop, ~150 cycles per entry on average, and a window miss enters anew */ \
   ".p2align 8\n"                                                      \
+  ZH_FAST_PAD                                                         \
   ".Lzh_byte_%=:\n\t"                                                 \
   ZH_CM_FAST_BYTE(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, "", "", "", "")       \
   ZH_CM_FAST_BYTE(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, "", "", "", "") \
@@ -314,7 +327,7 @@
   : [low] "+s"(low_), [high] "+s"(high_), [curr] "+s"(curr_), [k] "+s"(k_), [t] "+s"(t_), [h0] "+s"(h0_), \
     [bdone] "+s"(bdone_), [lu] "+v"(lu_), [vr] "+v"(vr_), [tag] "+v"(tag_), [nm] "+s"(nm_), [thr] "+s"(thr_), [code] "=s"(code_)          \
   : [klim] "s"(klim_), [bfe] "s"(bfe_), [hs] "s"(hs_), [vm] "v"(vm_), [bsa] "v"(bsa_),             \
-    [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [mqa] "v"(mqa_), [kb] "s"(kb_)                        \
+    [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [mqa] "v"(mqa_), [kb] "s"(kb_), [c24] "s"(0x1000000u)                      \
   : "memory", "scc", "vcc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",   \
     "s91", "s92", "s94", "v249", "v250", "v251", "v252", "v245", "s76", "s77", "v242", "v243", "v244")
 // Diagnostic build (zh_decode_cm_prof): the same loop with the cycles spent in the spin (wave A waiting for wave B: a window
@@ -379,6 +392,7 @@
   "s_mov_b32 s99, s97\n\t"                                            \
   "s_branch .Lzh_byte_%=\n\t"                                         \
   ".p2align 8\n"                                                      \
+  ZH_FAST_PAD                                                         \
   ".Lzh_byte_%=:\n\t"                                                 \
   ZH_CM_FAST_BYTE(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, ZH_STG_H0, ZH_STG_H1, ZH_STG_H2, ZH_STG_H3)       \
   ZH_CM_FAST_BYTE(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, ZH_STG_H0, ZH_STG_H1, ZH_STG_H2, ZH_STG_H3) \
@@ -448,7 +462,7 @@
   : [low] "+s"(low_), [high] "+s"(high_), [curr] "+s"(curr_), [k] "+s"(k_), [t] "+s"(t_), [h0] "+s"(h0_), \
     [bdone] "+s"(bdone_), [lu] "+v"(lu_), [vr] "+v"(vr_), [tag] "+v"(tag_), [nm] "+s"(nm_), [thr] "+s"(thr_), [code] "=s"(code_), [splo] "=s"(spin_lo_), [sphi] "=s"(spin_hi_), [nspin] "+s"(nspin_) \
   : [klim] "s"(klim_), [bfe] "s"(bfe_), [hs] "s"(hs_), [vm] "v"(vm_), [bsa] "v"(bsa_),             \
-    [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [mqa] "v"(mqa_), [kb] "s"(kb_)                        \
+    [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [mqa] "v"(mqa_), [kb] "s"(kb_), [c24] "s"(0x1000000u)                      \
   : "memory", "scc", "vcc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",   \
     "s91", "s92", "s94", "s96", "s97", "s98", "s99", "s100", "s101", "v249", "v250", "v251", "v252", "v245", "s76", "s77", "v242", "v243", "v244")
 // clang-format on
