@@ -51,6 +51,15 @@
 #define ZH_FAST_ADDC_IDX(J) "s_addc_u32 " J ", " J ", " J "\n\ts_add_u32 s80, s89, " J
 #define ZH_FAST_ADDC1_IDX(J) "s_addc_u32 " J ", 1, 1\n\ts_add_u32 s80, s89, " J
 
+// out-of-line blocks start on a 32-byte fetch window (each is entered by a taken branch and left by one: the padding is never run)
+#ifndef ZH_L1_COLD_ALIGN
+#define ZH_L1_COLD_ALIGN 1
+#endif
+#if ZH_L1_COLD_ALIGN
+#define ZH_FAST_COLD_ALIGN ".p2align 5\n"
+#else
+#define ZH_FAST_COLD_ALIGN ""
+#endif
 // Renormalisation (Decoder.cs:148-156): shift a coded byte in while the top bytes of low and
 // high agree; then the range test the next decode() would make (after the byte's last bit: ZH_FAST_CHK8).
 #define ZH_FAST_SHIFT_IN(N)                                           \
@@ -72,12 +81,14 @@
   "s_cbranch_scc1 .Lzh_rl" #N "_%=\n\t"
 // ... after the EOS flag (N = 0) or bit N (N = 1..7)
 #define ZH_FAST_RENORM(N)                                             \
+  ZH_FAST_COLD_ALIGN                                                  \
   ".Lzh_rn" #N "_%=:\n\t"                                             \
   ZH_FAST_SHIFT_IN(N)                                                 \
   ZH_FAST_CHK                                                         \
   "s_branch .Lzh_bk" #N "_%=\n\t"
 // ... after the byte's last bit
 #define ZH_FAST_RENORM_LAST(N, S)                                     \
+  ZH_FAST_COLD_ALIGN                                                  \
   ".Lzh_rn" #N "_%=:\n\t"                                             \
   ZH_FAST_SHIFT_IN(N)                                                 \
   ZH_FAST_CHK8(S)                                                     \
@@ -218,6 +229,7 @@
 #define ZH_FAST_OK_STAMPED(S) ".Lzh_okp" #S "_%="
 #define ZH_CM_FAST_COLD(S, E, N1, N2, N3, N4, N5, N6, N7, N8, SPIN_IN, SPIN_OK) \
   /* wave B is behind: re-read its progress counter a bounded number of times, then give up */ \
+  ZH_FAST_COLD_ALIGN                                                  \
   ".Lzh_fresh" #S "_%=:\n\t"                                          \
   ZH_FAST_FRESH_IN                                                    \
   SPIN_IN                                                             \
@@ -275,6 +287,7 @@
      words — every lane writes the same value to the same word: no exec switch —; the wave spins on C's answer and starts the \
      byte over: the lookup then hits.  The fresh window is stamped as if used 13 messages ago: nothing of it is outstanding with \
      wave B, 13 is what the ring can hold.  No candidate, or a window id beyond 16 bits: the C++ body serves it. */ \
+  ZH_FAST_COLD_ALIGN                                                  \
   ".Lzh_miss_%=:\n\t"                                                 \
   "s_cmp_ge_u32 s81, 0x10000\n\t"                                     \
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
@@ -408,6 +421,7 @@
      words — every lane writes the same value to the same word: no exec switch —; the wave spins on C's answer and starts the \
      byte over: the lookup then hits.  The fresh window is stamped as if used 13 messages ago: nothing of it is outstanding with \
      wave B, 13 is what the ring can hold.  No candidate, or a window id beyond 16 bits: the C++ body serves it. */ \
+  ZH_FAST_COLD_ALIGN                                                  \
   ".Lzh_miss_%=:\n\t"                                                 \
   "s_cmp_ge_u32 s81, 0x10000\n\t"                                     \
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
