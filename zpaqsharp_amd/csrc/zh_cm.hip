@@ -651,15 +651,18 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
             // hand-written loop for the common case (zh_cm_fast.h); the C++ body below is the same
             // algorithm and takes every byte the fast loop declines
             {
-              if (in.avail - in.k < 40 && in.avail == 256) in_seek(in, in_pos(in), lane);   // re-centre the chunk
+              if (in.avail - in.k < 49 && in.avail == 256) in_seek(in, in_pos(in), lane);   // re-centre the chunk (the fast loop wants 48 bytes ahead)
               uint32_t code;
               d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr); in.k = uni(in.k); in.avail = uni(in.avail);
               t = uni(t); h0 = uni(h0); b_done = uni(b_done); n_miss = uni(n_miss); thr = uni(thr);
               uint64_t f0 = 0, f1 = 0;
               const uint32_t t_in = t;
               if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(f0)::"memory"); }
-              if (LIKELY(d.curr - d.low <= d.high - d.low)) {   // the loop's invariant (an out-of-range state is the C++ body's to report)
-                const uint32_t klim = uni(in.avail >= 40 ? in.avail - 40 : 0u);
+              // the loop's invariant (an out-of-range state is the C++ body's to report); its lag compare is signed and uses 2^30 as "never"
+              if (LIKELY(d.curr - d.low <= d.high - d.low && t < 0x3e000000u)) {
+                // a byte consumes at most 9 x 4 coded bytes; the loop tests k < klim in the shadow of a byte's SEVENTH step, ahead of
+                // the renormalisations of its last two steps (at most 4 each): 48 ahead then is 40 at the next byte's start
+                const uint32_t klim = uni(in.avail >= 48 ? in.avail - 48 : 0u);
                 uint32_t vr = lane == 0 ? ring_addr + (t & (kRing - 1)) * 4u : dummy_addr;
                 if (PROF) {
                   uint32_t sp_lo = 0, sp_hi = 0, nsp = 0;

@@ -7,8 +7,8 @@
 // The loop only runs when nothing unusual can happen inside the byte.  It checks, before it
 // changes any state, that
 //   * at least 40 coded bytes are in the register-held chunk (a byte consumes at most 9 x 4), so
-//     a renormalisation never has to refill or can hit EOF;
-//   * the context's window is resident (otherwise wave B must swap it in);
+//     a renormalisation never has to refill or can hit EOF (the test is part of the lag compare, see below);
+//   * the context's window is resident (otherwise the swap wave brings it in: .Lzh_miss, served without leaving the loop);
 //   * wave B has finished every earlier byte that touched that window and the ring has room;
 //   * the EOS flag decodes as 0 (Decoder.cs:138; the state is in range by the invariant stated at the
 //     loop); an unprimed coder (curr == 0 < low) fails this test too, so priming needs no test of its own.
@@ -21,7 +21,7 @@
 // as the reference words it), and xor + compare + branch for the renormalisation, which is out of line.
 //
 // Register use: operands are allocated by the compiler; temporaries are the fixed registers
-// s76-s77, s80-s94 and v242-v245, v249-v252 (declared as clobbers).  exec is all ones on entry and exit.
+// s76-s77, s80-s94 and v237-v245, v249-v252 (declared as clobbers).  exec is all ones on entry and exit.
 #pragma once
 
 // clang-format off
@@ -112,57 +112,70 @@
 // of message t (the other lanes of `vr` hold the addresses of their own dummy words: no exec switch around the write);
 // then the ring address of lane 0 steps on (v_bfi keeps the other lanes), t, the slot's last-use stamp (vcc still is
 // the one-hot lane mask of the window lookup: nothing in the loop writes vcc after it), h[0]
-// (round 4) Everything of a byte's bookkeeping that is vector work, or can be made vector work, sits in the SHADOW of a
-// v_readlane: the first SALU instruction behind a VALU instruction that writes an SGPR issues ~21 cycles after it whatever it
-// reads, and up to three or four VALU instructions in between are free (tools/ubench/sgprw_bench,
-// profiles/r04/ubench_sgprw.txt; same-box A/Bs of every step: profiles/r04/ab_notes.txt, calls 14-19):
-//   step 1: wave B's progress counter, read from LDS with the byte's probabilities, is taken over (a second SGPR-writing
-//           VALU instruction back to back costs one issue slot, not a second stall): the NEXT byte's lag test works on a
-//           counter one byte old instead of one that is only refreshed after a failed test;
-//   step 2: the window's last-use stamp t + 1 (vcc still is the one-hot lane mask of the window lookup: nothing in the loop
-//           writes vcc after it);
-//   step 3: v242 = max(last use, t + 1 - 13) — the next byte's lag test as ONE compare: wave B may be at most
-//           min(messages since the window's last use, 13) behind,  t - bdone <= min(t - lu, 13)  <=>  max(lu, t - 13) <= bdone
-//           (signed: t - 13 is negative at first; lanes that stand for no slot carry -1 and are masked by the lookup);
-//   steps 6, 7: the message without the byte, tag(t) << 25 | slot;
-//   step 8: the next ring address of lane 0 (v_bfi keeps the other lanes, which point at dummy words: no exec switch around
-//           the write; v251 is free since the nibble switch).
-// The epilogue then is: byte = (j << 4) + j2 - 272, message = byte << 15 | (tag | slot) by one v_lshl_or, the write, t, h[0].
+// (round 4) Two rules of a lone wave's instruction stream shape this loop (profiles/r04/ab_notes.txt, calls 14-26):
+//
+// 1. The first SALU instruction behind a VALU instruction that writes an SGPR (v_readlane, v_cmp) issues ~21 cycles after it,
+//    whatever it reads; three to four VALU instructions in between are free (tools/ubench/sgprw_bench,
+//    profiles/r04/ubench_sgprw.txt).  So everything of a byte's bookkeeping that is vector work, or can be made vector work,
+//    sits in the SHADOW of a step's v_readlane:
+//      step 1: wave B's progress counter, read from LDS with the byte's probabilities, is taken over (a second SGPR-writing
+//              VALU instruction back to back costs one issue slot, not a second stall): the NEXT byte's lag test works on a
+//              counter one byte old instead of one refreshed only after a failed test;  tag | slot of the message begins;
+//              v238 = t + 1 - 13 (t lives in a VGPR, v241, inside the loop: nothing scalar on the hot path needs it)
+//      step 2: the window's last-use stamp t + 1 (vcc still is the one-hot lane mask of the window lookup: nothing in the loop
+//              writes vcc after it)
+//      step 3: the message without the byte, tag(t) << 25 | slot
+//      steps 5, 6: the next ring address of lane 0 (v_bfi keeps the other lanes, which point at dummy words: no exec switch
+//              around the write; v251 is free since the nibble switch)
+//      steps 7, 8: v242 = max(last use, t + 1 - 13, (k - klim) | 2^30) — the NEXT byte's lag test and its chunk test as ONE
+//              compare against wave B's counter: wave B may be at most min(messages since the window's last use, 13) behind,
+//              t - bdone <= min(t - lu, 13)  <=>  max(lu, t - 13) <= bdone  (signed: t - 13 is negative at first; lanes that
+//              stand for no slot carry -1 and are masked by the lookup; zh_cm.hip keeps t below 2^30 - 2^25), and k - klim is
+//              negative while enough coded bytes are ahead.  k is read in step 7, before the renormalisations of the last two
+//              steps (at most 4 bytes each): klim = avail - 48 leaves the 40 a byte can consume.  The out-of-line wait tells
+//              the two reasons apart.
+//    The epilogue then is: byte = (j << 4) + j2 - 272, message = byte << 15 | (tag | slot) by one v_lshl_or, the write, h[0].
+// 2. Instruction fetch does not run ahead across a conditional branch: a NOT-TAKEN branch whose next two instructions do not
+//    lie in the branch's own 32-byte window costs ~19 cycles (the same loop shifted in 4-byte steps: 580 .. 664 MB/s, period
+//    32 bytes).  Every bit step therefore is exactly 64 bytes (the constants of the renormalisation tests in SGPRs, s_addk
+//    for the -272, v_nop in the shadows as free filler), the nibble switch 32, the byte 672, and ZH_L1_PAD puts a step's
+//    v_readlane 16 bytes into a window: its branch sits at 12, the v_readlane and the first shadow instruction behind it.
+//    ANY edit of the hot path has to keep this (llvm-objdump -d with addresses; then sweep ZH_L1_PAD).
 // Measured and not kept: the step with the next bit's probability fetched both ways (pairs of children per lane, two v_readlane
 // while the split is computed, one s_cselect by the bit: the chain s_addc -> v_readlane -> s_mul_hi becomes s_cselect ->
 // s_mul_hi) — 522 against 595 MB/s: the ~21 cycles behind a v_readlane are not a dependency a schedule can cover.
 #define ZH_FAST_READ_BSEQ "ds_read_b32 v245, %[bsa]\n\t"
-#define ZH_FAST_SHADOW1 "v_readfirstlane_b32 %[bdone], v245\n\tv_mov_b32_e32 v243, s82\n\tv_nop\n\t"
-#define ZH_FAST_SHADOW2 "v_add_u32_e64 v252, %[t], 1\n\tv_cndmask_b32_e32 %[lu], %[lu], v252, vcc\n\t"
-#define ZH_FAST_SHADOW3 "v_add_u32_e64 v244, %[t], -12\n\tv_max_i32_e32 v242, v244, %[lu]\n\t"
-#define ZH_FAST_SHADOW4 "v_lshl_or_b32 v243, %[t], 25, v243\n\tv_nop\n\t"
+#define ZH_FAST_SHADOW1 "v_readfirstlane_b32 %[bdone], v245\n\tv_mov_b32_e32 v243, s82\n\tv_add_u32_e32 v238, -12, v241\n\t"
+#define ZH_FAST_SHADOW2 "v_add_u32_e32 v252, 1, v241\n\tv_cndmask_b32_e32 %[lu], %[lu], v252, vcc\n\tv_nop\n\t"
+#define ZH_FAST_SHADOW3 "v_lshl_or_b32 v243, v241, 25, v243\n\tv_nop\n\t"
+#define ZH_FAST_SHADOW4 "v_nop\n\tv_nop\n\tv_nop\n\t"
 #define ZH_FAST_SHADOW5 "v_add_u32_e32 v251, 4, %[vr]\n\tv_nop\n\t"
 #define ZH_FAST_SHADOW6 "v_bfi_b32 v251, %[vm], v251, %[vr]\n\t"
-#define ZH_FAST_SHADOW7 "v_nop\n\tv_nop\n\t"
-#define ZH_FAST_SHADOW8 "v_nop\n\tv_nop\n\tv_nop\n\t"
+#define ZH_FAST_SHADOW7 "v_sub_u32_e32 v239, %[k], v240\n\tv_or_b32_e32 v239, v237, v239\n\t"
+#define ZH_FAST_SHADOW8 "v_max3_i32 v242, v238, %[lu], v239\n\tv_add_u32_e32 v241, 1, v241\n\t"
 // v242 for THIS byte: at loop entry, and after a miss has re-stamped a slot
-#define ZH_FAST_LAGV "v_add_u32_e64 v244, %[t], -13\n\tv_max_i32_e32 v242, v244, %[lu]\n\t"
+#define ZH_FAST_LAGV "v_add_u32_e32 v244, -13, v241\n\tv_sub_u32_e32 v239, %[k], v240\n\tv_or_b32_e32 v239, v237, v239\n\tv_max3_i32 v242, v244, %[lu], v239\n\t"
+// loop entry: t, the chunk limit and 2^30 into their VGPRs;  ZH_FAST_T: t back into its SGPR (out-of-line paths, exit)
+#define ZH_FAST_ENTRY "v_mov_b32_e32 v241, %[t]\n\tv_mov_b32_e32 v240, %[klim]\n\tv_mov_b32_e32 v237, 0x40000000\n\t"
+#define ZH_FAST_T "v_readfirstlane_b32 %[t], v241\n\t"
 #define ZH_FAST_EPILOGUE                                              \
   "s_lshl4_add_u32 s92, s90, s91\n\t"                                 \
   "s_addk_i32 s92, 0xfef0\n\t"                                        \
   "v_lshl_or_b32 v250, s92, 15, v243\n\t"                             \
   "ds_write_b32 %[vr], v250\n\t"                                      \
   "v_mov_b32_e32 %[vr], v251\n\t"                                     \
-  "s_add_u32 %[t], %[t], 1\n\t"                                       \
   "s_lshl_b32 %[h0], s92, %[hs]\n\t"
 // window lookup (lane s of `tag` holds the window id cached in slot s) and lag test; the out-of-line wait computes the
 // allowance min(t - lu[slot], 13) itself
 #define ZH_FAST_LOOKUP(S)                                             \
   "s_bfe_u32 s81, %[h0], %[bfe]\n\t"                                  \
   "v_cmp_eq_u32_e32 vcc, s81, %[tag]\n\t"                             \
-  "v_nop\n\t"                                                         \
   "v_cmp_gt_i32_e64 s[76:77], v242, %[bdone]\n\t"                     \
-  "v_nop\n\tv_nop\n\tv_nop\n\t"                                     \
   "s_cbranch_vccz .Lzh_miss_%=\n\t"                                   \
   "s_ff1_i32_b64 s82, vcc\n\t"                                        \
   "s_and_b64 s[76:77], s[76:77], vcc\n\t"                             \
   "s_cbranch_scc1 .Lzh_fresh" #S "_%=\n"
-#define ZH_FAST_FRESH_IN "v_readlane_b32 s83, %[lu], s82\n\ts_sub_u32 s83, %[t], s83\n\ts_min_u32 s83, s83, 13\n\t"
+#define ZH_FAST_FRESH_IN ZH_FAST_T "s_cmp_ge_u32 %[k], %[klim]\n\ts_cbranch_scc1 .Lzh_slow_%=\n\tv_readlane_b32 s83, %[lu], s82\n\ts_sub_u32 s83, %[t], s83\n\ts_min_u32 s83, s83, 13\n\t"
 // the eight bit steps: first nibble, node j in lane j of v249 (high half); second nibble, group n1 = quad (n1 & 3), element
 // n1 >> 2 of the four candidates a lane holds in v[250:251]
 #define ZH_FAST_BITS(N1, N2, N3, N4, N5, N6, N7, N8)                  \
@@ -184,7 +197,8 @@
 // s76:s77 lag-test mask   s80 lane of the next second-nibble step / scratch   s81 window id   s82 slot
 // s83 allowance of the out-of-line wait / shift of the nibble switch   s84-s88 step scratch   s89 first lane of the group's quad
 // s90 j (16|n1) s91 j2 (16|n2)  s92 byte   s94 probability
-// v242 lag-test operand   v243 message without the byte   v244 scratch   v245 wave B's counter as read from LDS
+// v237 2^30   v238 t + 1 - 13   v239 chunk term   v240 klim   v241 t   v242 lag-test operand   v243 message without the byte
+// v244 scratch   v245 wave B's counter as read from LDS
 // v250:v251 four second-nibble probabilities / selected one (v251 later: next ring address)   v252 scratch
 // v249 first-nibble probabilities << 16 (loaded into the high half: ds_read_u16_d16_hi; its low half stays zero)
 //
@@ -207,16 +221,14 @@
   "ds_read_u16_d16_hi v249, v252\n\t"                                 \
   "ds_read_b64 v[250:251], v250\n\t"                                  \
   ZH_FAST_READ_BSEQ                                                   \
-  /* at least 40 coded bytes in the chunk (klim = avail - 40, or 0) */ \
-  "s_cmp_ge_u32 %[k], %[klim]\n\t"                                    \
-  "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
+  /* (enough coded bytes in the chunk, k < klim: part of the lag compare, ZH_FAST_SHADOW7 / 8) */ \
   /* EOS flag (p = 0): y = curr <= low; leave when y = 1 (or the coder is unprimed) */ \
   "s_cmp_le_u32 %[curr], %[low]\n\t"                                  \
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
   "s_add_u32 %[low], %[low], 1\n\t"                                   \
-  "s_xor_b32 s84, %[high], %[low]\n\t"                                \
-  "s_cmp_lt_u32 s84, %[c24]\n\t"                                      \
-  "s_cbranch_scc1 .Lzh_rn" #E "_%=\n"                                 \
+  /* the state was normalised (every split is followed by its renormalisation): the + 1 matters only when it carries into the top byte */ \
+  "s_and_b32 s84, %[low], %[c24m]\n\t"                                \
+  "s_cbranch_scc0 .Lzh_e0" #S "_%=\n"                                 \
   ".Lzh_bk" #E "_%=:\n\t"                                             \
   "s_waitcnt lgkmcnt(0)\n\t"                                          \
   H2                                                                  \
@@ -245,6 +257,12 @@
   "s_cmp_lg_u32 s80, 0\n\t"                                           \
   "s_cbranch_scc1 .Lzh_spin" #S "_%=\n\t"                             \
   "s_branch .Lzh_slow_%=\n\t"                                         \
+  ZH_FAST_COLD_ALIGN                                                  \
+  ".Lzh_e0" #S "_%=:\n\t"                                             \
+  "s_xor_b32 s84, %[high], %[low]\n\t"                                \
+  "s_cmp_lt_u32 s84, %[c24]\n\t"                                      \
+  "s_cbranch_scc0 .Lzh_bk" #E "_%=\n\t"                               \
+  "s_branch .Lzh_rn" #E "_%=\n\t"                                     \
   ZH_FAST_RENORM(E)                                                   \
   ZH_FAST_RENORM(N1)                                                  \
   ZH_FAST_RENORM(N2)                                                  \
@@ -259,9 +277,9 @@
   "s_branch .Lzh_slow_%=\n"
 
 // Where the loop lies against its 256-byte alignment (dwords of padding behind the .p2align, jumped over at entry):
-// -DZH_L1_PAD=n shifts the unchanged body by 4n bytes (profiles/r04/ab_notes.txt, call 22)
+// -DZH_L1_PAD=n shifts the unchanged body by 4n bytes (profiles/r04/ab_notes.txt, calls 22, 26)
 #ifndef ZH_L1_PAD
-#define ZH_L1_PAD 5
+#define ZH_L1_PAD 4
 #endif
 #define ZH_STR_(x) #x
 #define ZH_STR(x) ZH_STR_(x)
@@ -269,6 +287,7 @@
 #define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_, thr_, nm_, mqa_, kb_) \
   asm volatile(                                                       \
   "v_mov_b32_e32 v249, 0\n\t"                                         \
+  ZH_FAST_ENTRY                                                       \
   ZH_FAST_LAGV                                                        \
   "s_branch .Lzh_byte_%=\n\t"   /* over the alignment padding: up to 63 s_nop, ~150 cycles per entry on average, and a window miss enters anew */ \
   ".p2align 8\n"                                                      \
@@ -289,6 +308,7 @@
      wave B, 13 is what the ring can hold.  No candidate, or a window id beyond 16 bits: the C++ body serves it. */ \
   ZH_FAST_COLD_ALIGN                                                  \
   ".Lzh_miss_%=:\n\t"                                                 \
+  ZH_FAST_T                                                           \
   "s_cmp_ge_u32 s81, 0x10000\n\t"                                     \
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
   "v_cmp_gt_u32_e32 vcc, %[thr], %[lu]\n\t"                           \
@@ -337,12 +357,13 @@
   "s_waitcnt lgkmcnt(0)\n\t"                                          \
   "s_mov_b32 %[code], 0\n"                                            \
   ".Lzh_end_%=:\n\t"                                                  \
+  ZH_FAST_T                                                           \
   : [low] "+s"(low_), [high] "+s"(high_), [curr] "+s"(curr_), [k] "+s"(k_), [t] "+s"(t_), [h0] "+s"(h0_), \
     [bdone] "+s"(bdone_), [lu] "+v"(lu_), [vr] "+v"(vr_), [tag] "+v"(tag_), [nm] "+s"(nm_), [thr] "+s"(thr_), [code] "=s"(code_)          \
   : [klim] "s"(klim_), [bfe] "s"(bfe_), [hs] "s"(hs_), [vm] "v"(vm_), [bsa] "v"(bsa_),             \
-    [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [mqa] "v"(mqa_), [kb] "s"(kb_), [c24] "s"(0x1000000u)                      \
+    [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [mqa] "v"(mqa_), [kb] "s"(kb_), [c24] "s"(0x1000000u), [c24m] "s"(0xffffffu)                      \
   : "memory", "scc", "vcc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",   \
-    "s91", "s92", "s94", "v249", "v250", "v251", "v252", "v245", "s76", "s77", "v242", "v243", "v244")
+    "s91", "s92", "s94", "v249", "v250", "v251", "v252", "v245", "s76", "s77", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244")
 // Diagnostic build (zh_decode_cm_prof): the same loop with the cycles spent in the spin (wave A waiting for wave B: a window
 // being swapped in, or B behind by more than the window's lag allowance) summed into spin_ (s96-s101 are scratch here).
 // -DZH_L1_STAGE=n (n = 1..4) turns the diagnostic loop into a STAGE build instead: the cycles between two points of the byte
@@ -396,6 +417,7 @@
 #define ZH_CM_FAST_LOOP_PROF(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_, thr_, nm_, mqa_, kb_, spin_lo_, spin_hi_, nspin_) \
   asm volatile(                                                       \
   "v_mov_b32_e32 v249, 0\n\t"                                         \
+  ZH_FAST_ENTRY                                                       \
   ZH_FAST_LAGV                                                        \
   "s_mov_b32 s100, 0\n\t"                                             \
   "s_mov_b32 s101, 0\n\t"                                             \
@@ -423,6 +445,7 @@
      wave B, 13 is what the ring can hold.  No candidate, or a window id beyond 16 bits: the C++ body serves it. */ \
   ZH_FAST_COLD_ALIGN                                                  \
   ".Lzh_miss_%=:\n\t"                                                 \
+  ZH_FAST_T                                                           \
   "s_cmp_ge_u32 s81, 0x10000\n\t"                                     \
   "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
   "v_cmp_gt_u32_e32 vcc, %[thr], %[lu]\n\t"                           \
@@ -471,12 +494,13 @@
   "s_waitcnt lgkmcnt(0)\n\t"                                          \
   "s_mov_b32 %[code], 0\n"                                            \
   ".Lzh_end_%=:\n\t"                                                  \
+  ZH_FAST_T                                                           \
   "s_mov_b32 %[splo], s100\n\t"                                       \
   "s_mov_b32 %[sphi], s101\n\t"                                       \
   : [low] "+s"(low_), [high] "+s"(high_), [curr] "+s"(curr_), [k] "+s"(k_), [t] "+s"(t_), [h0] "+s"(h0_), \
     [bdone] "+s"(bdone_), [lu] "+v"(lu_), [vr] "+v"(vr_), [tag] "+v"(tag_), [nm] "+s"(nm_), [thr] "+s"(thr_), [code] "=s"(code_), [splo] "=s"(spin_lo_), [sphi] "=s"(spin_hi_), [nspin] "+s"(nspin_) \
   : [klim] "s"(klim_), [bfe] "s"(bfe_), [hs] "s"(hs_), [vm] "v"(vm_), [bsa] "v"(bsa_),             \
-    [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [mqa] "v"(mqa_), [kb] "s"(kb_), [c24] "s"(0x1000000u)                      \
+    [cur] "v"(cur_), [la] "v"(la_), [lb] "v"(lb_), [mqa] "v"(mqa_), [kb] "s"(kb_), [c24] "s"(0x1000000u), [c24m] "s"(0xffffffu)                      \
   : "memory", "scc", "vcc", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",   \
-    "s91", "s92", "s94", "s96", "s97", "s98", "s99", "s100", "s101", "v249", "v250", "v251", "v252", "v245", "s76", "s77", "v242", "v243", "v244")
+    "s91", "s92", "s94", "s96", "s97", "s98", "s99", "s100", "s101", "v249", "v250", "v251", "v252", "v245", "s76", "s77", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244")
 // clang-format on
