@@ -1,0 +1,10 @@
+#!/bin/bash
+# L1: the EOS test between the LDS reads, so that its branch and the two instructions behind it share a fetch window (G1), same box
+mkdir -p gpurun_out/r04
+cp build/ab/libG1.so zpaqsharp_amd/libzpaqhip.so
+bash tools/r04_l1.sh || exit 1
+for v in G0 G1 G0 G1; do
+  cp build/ab/lib$v.so zpaqsharp_amd/libzpaqhip.so
+  for K in T X R; do timeout -k 10 120 python3 bench.py --model l1 --kind $K --blocks 256 --block-bytes 1048576 --no-extras --no-cpu-baseline --cache-dir /tmp/zc 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', '$K', round(d['value'],1), d['bit_exact'])"; done
+done | tee gpurun_out/r04/ab28.txt
+cp build/ab/libG1.so zpaqsharp_amd/libzpaqhip.so
