@@ -377,7 +377,11 @@ __device__ __forceinline__ void decode_cm_body(const ZhLaunch &L, CmLdsT<NW, NP>
   uint64_t tprev = 0, t_exit = 0, t_pub = 0;           // PROF: stamps of the miss path (asm loop left, miss published)
   bool was_miss = false;
   // a block = three wavefronts: A (decoder), B (model, probability cache, output), C (window swaps)
-  const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, pair = NP > 1 ? wid / 3u : 0u, wave = NP > 1 ? wid - pair * 3u : wid;
+  // Two blocks per workgroup: wavefronts in the order A0 A1 B0 B1 C0 C1.  A CU hands its wavefronts to its four SIMDs in turn, so
+  // each decoder wave shares its SIMD only with its own swap wave (asleep unless that decoder waits for it), the two model waves
+  // have a SIMD each.  (Round 4, first form: A0 B0 C0 A1 B1 C1 — decoder 0 shared its SIMD with model wave 1, decoder 1 had one
+  // to itself, and the launch waited for decoder 0.)
+  const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, pair = NP > 1 ? wid % NP : 0u, wave = NP > 1 ? wid / NP : wid;
   CmTabs &T = SS.T;
   CmBlkT<NW> &S = SS.B[pair];
 
