@@ -29,6 +29,8 @@ extern "C" hipError_t zh_launch_chain(const ZhLaunch *L, uint32_t grid, hipStrea
 extern "C" hipError_t zh_launch_cm_prof(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_chain2(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof);
 extern "C" int zh_chain2_has(uint32_t spec);
+extern "C" hipError_t zh_launch_nibble(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof);
+extern "C" int zh_nibble_has(uint32_t spec);
 static size_t pool_trim_device(int device, size_t keep);   // idle contexts of zpaqhip_decompress_multi's pool (below)
 #ifdef ZH_WITH_CHAIN3   // make EXPERIMENTS=1: tools/experiments/zh_chain3.hip (three-wave form, measured slower; not in the product build)
 extern "C" hipError_t zh_launch_chain3(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int variant);
@@ -449,6 +451,8 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     else if (g > ZH_FAM_CHAIN && zh_chain3_has(g - ZH_FAM_CHAIN) && (opts.kernel == 7 || opts.kernel == 8))   // decoder ‖ model ‖ helper wave: experiment build only
       HIPCHK(zh_launch_chain3(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof ? 2 : opts.kernel == 7));
 #endif
+    else if (g > ZH_FAM_CHAIN && zh_nibble_has(g - ZH_FAM_CHAIN) && opts.kernel == 9)   // nibble-at-a-time form (zh_nibble.hip)
+      HIPCHK(zh_launch_nibble(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));
     else if (g > ZH_FAM_CHAIN && zh_chain2_has(g - ZH_FAM_CHAIN) && opts.kernel != 5)   // per-model bit loop (zh_chain2.hip)
       HIPCHK(zh_launch_chain2(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));
     else if (g >= ZH_FAM_CHAIN) {
