@@ -191,10 +191,7 @@ def issue_bound(base_model, kms, plain_bytes, waves):
             "decoder_wave_instr_per_plain_byte": n, "instr_source": src,
             "ceiling_cycles_per_instr": ISSUE_CYCLES_PER_INSTR,
             "frac_of_issue_ceiling": (n * ISSUE_CYCLES_PER_INSTR / cyc) if n else None,
-            "note": "the operative bound is the dependent instruction chain of the wave that owns a block: the block's speed is "
-                    "(cycles per byte)^-1 and the floor is 4 cycles per instruction of that wave (static count); "
-                    "the HBM fraction above is kept for reference (traffic is far below algorithmic bytes where tables "
-                    "live in LDS, above them where the helper wave speculates over 16 candidate bytes)"}
+            "note": "bound = one wave's instruction chain per block: DESIGN.md 4"}
 
 
 def method_streams(z, synth, ctx, kib=4096, blocks=256, threads=None):
@@ -333,6 +330,63 @@ def sweep_counts(share):
     if q:
         top = min(top, max(32, int(4 * q)))
     return sorted({c for c in (8, 16, 32, 64, 128, top) if c <= top})
+
+
+def _r(x, n=2):
+    return round(x, n) if isinstance(x, float) else x
+
+
+def compact_line(line):
+    """The ONE line bench.py prints, kept under 8 KB (the driver records the last 8 KB of the output): the contract's keys in full,
+    roofline and cpu_baseline without their prose, and every other measured configuration as one short record — the
+    per-config summary comes LAST.  The unabridged line is written to gpurun_out/bench_full.json."""
+    def roof(r):
+        iss = r.get("issue") or {}
+        return {"bound": r["bound"], "achieved": _r(r["achieved"], 3), "peak": r["peak"], "unit": r["unit"], "frac": _r(r["frac"], 5),
+                "traffic": r.get("traffic"), "kernel_ms": _r(r["kernel_ms"], 1),
+                "cycles_per_byte": _r(iss.get("cycles_per_plain_byte_per_block"), 0), "instr_per_byte": iss.get("decoder_wave_instr_per_plain_byte"),
+                "frac_of_issue_ceiling": _r(iss.get("frac_of_issue_ceiling"), 3)}
+
+    def cpu(c):
+        return None if not c else {"value": _r(c["value"]), "unit": c["unit"], "cores": c.get("cores", c.get("threads")), "kind": c.get("kind", "port"),
+                                   "sample": c["sample"][:110]}
+    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                "dtype", "data", "bit_exact") if k in line}
+    if "error" in line:
+        out["error"] = line["error"]
+    cfg = dict(line["config"])
+    cfg["workload"] = cfg["workload"][:200]
+    cfg["parallelism"] = cfg["parallelism"][:120]
+    out["config"] = cfg
+    out["roofline"] = roof(line["roofline"])
+    out["roofline"]["traffic_note"] = (line["roofline"].get("traffic_source") or line["roofline"].get("traffic_note") or "")[:90]
+    out["cpu_baseline"] = cpu(line.get("cpu_baseline"))
+    if "value_host_to_host" in line:
+        out["value_host_to_host"] = _r(line["value_host_to_host"])
+        h = line["host_to_host"]
+        out["host_to_host"] = {k: _r(h[k]) for k in ("value", "h2d_ms", "kernel_ms", "d2h_ms", "bit_exact")}
+    if "cpu_all_cores" in line:
+        out["cpu_all_cores"] = {"value": _r(line["cpu_all_cores"]["value"]), "threads": line["cpu_all_cores"]["threads"]}
+        out["cpu_all_cores_sweep"] = [[p["threads"], p["value"]] for p in line.get("cpu_all_cores_sweep", [])]
+        sh = line.get("cpu_share", {})
+        out["cpu_share"] = [sh.get("host_logical_cores"), sh.get("affinity_cores"), sh.get("cgroup_cpu_quota_cores")]
+    if "method_streams" in line:
+        out["method_streams"] = [{"method": m["method"], "kernel": m.get("kernel"), "value": _r(m["value"], 1), "kernel_MBps": _r(m["kernel_MBps"], 1),
+                                  "bit_exact": m["bit_exact"]} for m in line["method_streams"]]
+    if "other_configs" in line:                                  # last: one record per BASELINE-shaped configuration
+        oc = []
+        for r in line["other_configs"]:
+            rec = {"config": r["config"][:40], "workload": r["workload"][:60], "value": _r(r["value"]), "unit": "MB/s", "bit_exact": r["bit_exact"],
+                   "roofline": roof(r["roofline"])}
+            if r.get("cpu_baseline"):
+                rec["cpu_baseline"] = {"value": _r(r["cpu_baseline"]["value"]), "cores": 1, "kind": "port"}
+            if r.get("cpu_all_cores"):
+                rec["cpu_all_cores"] = [_r(r["cpu_all_cores"]["value"]), r["cpu_all_cores"]["threads"]]
+            if r.get("cpu_all_cores_sweep"):
+                rec["cpu_sweep"] = [[p["threads"], p["value"]] for p in r["cpu_all_cores_sweep"]]
+            oc.append(rec)
+        out["other_configs"] = oc
+    return out
 
 
 def main():
@@ -571,7 +625,13 @@ def main():
     if not ok:
         line["value"] = 0.0
         line["error"] = "GPU output is not bit-exact"
-    print(json.dumps(line))
+    try:                                                    # everything, for the builder: profiles/ keeps copies of this file
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w") as f:
+            json.dump(line, f)
+    except OSError:
+        pass
+    print(json.dumps(compact_line(line), separators=(",", ":")))
     if world > 1:
         dist.destroy_process_group()
 

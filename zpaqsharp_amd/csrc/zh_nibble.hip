@@ -36,6 +36,10 @@ using namespace zhdev;
 #define C2_TOUCH 0
 #define C2_FINDB 1
 #include "zh_c2_common.h"
+#include "zh_nb_fast.h"
+#ifndef ZH_NB_ASM
+#define ZH_NB_ASM 1                           /* 0: nb_fast runs the C++ form of its loop (A/B runs, the *_prof kernels) */
+#endif
 
 namespace {
 
@@ -61,6 +65,10 @@ struct alignas(16) NbLds {
   uint32_t seloff[kSpecUnits][16];
   uint32_t mb_nib, mb_byte, mb_ready;
   uint32_t mb_cmd, mb_ack, mb_model;
+  uint32_t fxs[96];                           // nb_fast: scalars in and out (kFx*)
+  uint32_t fxv[64][64];                       // ... and per-lane words (NbV, the coded chunk, the parked output)
+  uint32_t fxk[kNbK_count][64];               // zh_nb_fast.h: per-lane constants of the assembly loop
+  uint32_t fxa[kNbS_count][64];               // ... and the per-lane state it loads and stores
   uint32_t hreg[kHWords];
   uint8_t mreg[kMBytes];
   uint32_t r[256], pr[256];
@@ -97,21 +105,634 @@ __device__ __forceinline__ int sum8(int v) {
   return v;
 }
 
+// ---- per-lane constants: the component this lane stands for and the path its group walks ----------------------------
+template <class SP>
+struct NbK {
+  static constexpr uint32_t NC = SP::id == 1 ? 2u : 8u;          // lanes of a group
+  static constexpr uint32_t NG = 8u;                               // groups: the 3-bit prefixes of a nibble's path
+  static constexpr uint64_t kII = SP::icm | SP::isse;
+  static constexpr uint32_t mx_m4 = SP::mix_m[0] * 4u;
+  uint32_t lane, ci, g, b1, b2, b3;
+  bool act, canon, l_isse, l_ii, l_match, l_feed;
+  uint32_t sh2, sh3, sh4, node[5], pre[5], ybit[4];
+  uint32_t hto, ht_mask, cmo, cm_mask, sizebits2, tab, wrow, wrow_mask, unit, un_;
+  int isse_m;
+  uint32_t cshift;
+  int pself, mx_rate;
+  uint32_t vo_mix, mx_base, mx_size1;
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint8_t *slot_mem;
+};
+// ---- per-lane state carried from nibble to nibble and from byte to byte (the same in every group) ---------------------
+struct NbV {
+  uint32_t hv;                                        // h[component] (Predictor.cs:469)
+  uint32_t rowoff;                                    // place of the hash row of the current nibble (in S.slot[ci] and below)
+  uint32_t row_x, row_q1, row_q2, row_q3;             // the row as it was when the nibble began (zero for components without a table)
+  uint32_t rowvalid;
+  int mwl[5];                                         // mixer: this lane's weight in the row of level d of the current nibble
+  uint32_t mrowl[5];                                  // ... and its buffer offset
+  uint32_t mx_rb;                                     // this lane's buffer offset in row 0 of the byte's block of mixer rows
+  uint32_t m_len, m_ptr, m_limit, m_byte;             // MATCH (Predictor.cs:273-287, 382-411): the Component fields
+  int pm0, pm1;                                       // stretch of -+dt2k[len] for this byte; 0 once the match has failed
+  uint32_t cm_pre, va_pre, vb_pre, mbn_pre, mbc_pre;  // see zh_chain2.hip (match_prefetch)
+  v4u oldb; uint32_t oldb_off, oldb_valid;            // the row written back at the last byte boundary
+  v4u old1; uint32_t old1_off, old1_valid;            // the first nibble's row as it was evicted
+  int w1_new;                                         // mixer: row c8 = 1 of the byte's block after the first nibble
+};
+constexpr int kNbVWords = sizeof(NbV) / 4;
+static_assert(sizeof(NbV) % 4 == 0 && kNbVWords + 2 <= 64, "nb_fast exchange area");
+struct NbProf { uint64_t prof[16]; uint64_t tprev; };
+
+#undef NB_STAMP
+#define NB_STAMP(i)                                                                                  \
+  do {                                                                                               \
+    if (PROF) {                                                                                      \
+      uint64_t now_;                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+      P.prof[i] += now_ - P.tprev;                                                                   \
+      P.tprev = now_;                                                                                \
+    }                                                                                                \
+  } while (0)
+
+template <class SP, class LDS>
+__device__ __forceinline__ void nb_setup(NbK<SP> &K, LDS &S, const ZhModel *M, uint8_t *slot_mem, uint32_t lane) {
+  constexpr uint32_t NC = NbK<SP>::NC, NG = NbK<SP>::NG;
+  K.lane = lane; K.ci = lane & (NC - 1u); K.g = (lane / NC) & (NG - 1u);
+  K.act = lane < NC * NG; K.canon = lane < NC;            // min: lanes 16-63 repeat lanes 0-15 and never write
+  K.b1 = (K.g >> 2) & 1u; K.b2 = (K.g >> 1) & 1u; K.b3 = K.g & 1u;
+  K.l_isse = (SP::isse >> K.ci) & 1; K.l_ii = (NbK<SP>::kII >> K.ci) & 1;
+  K.l_match = SP::match_lane >= 0 && K.ci == (uint32_t)SP::match_lane;
+  K.sh2 = 16u + 8u * K.b1;                               // node 2 + b1: byte 2 / 3 of row dword 0
+  K.sh3 = 8u * (2u * K.b1 + K.b2);                       // node 4 + 2 b1 + b2: a byte of dword 1
+  K.sh4 = 8u * (2u * K.b2 + K.b3);                       // node 8 + 4 b1 + 2 b2 + b3: a byte of dword 2 (b1 = 0) / 3
+  K.node[0] = 0; K.node[1] = 1u; K.node[2] = 2u + K.b1; K.node[3] = 4u + 2u * K.b1 + K.b2; K.node[4] = 8u + 4u * K.b1 + 2u * K.b2 + K.b3;
+  K.pre[0] = 0; K.pre[1] = 0; K.pre[2] = K.b1; K.pre[3] = 2u * K.b1 + K.b2; K.pre[4] = 4u * K.b1 + 2u * K.b2 + K.b3;   // c8 of level d = (c8 of the nibble << (d-1)) + pre[d]
+  K.ybit[0] = 0; K.ybit[1] = K.b1; K.ybit[2] = K.b2; K.ybit[3] = K.b3;     // the bit this group assumes at level d (d = 1..3)
+  K.unit = (uint32_t)__builtin_popcountll(NbK<SP>::kII & ((1ull << K.ci) - 1));
+  K.un_ = K.unit < (uint32_t)kSpecUnits ? K.unit : 0u;
+  const ZhComp *mycp = &M->comp[K.ci < SP::n ? K.ci : 0];
+  K.hto = K.l_ii || K.l_match ? (uint32_t)mycp->ht_off : 0u; K.ht_mask = mycp->ht_mask;
+  K.cmo = (uint32_t)mycp->cm_off; K.cm_mask = mycp->cm_mask;
+  K.sizebits2 = (uint32_t)mycp->arg[0] + 2;
+  K.tab = K.l_ii ? lds_off(&S.ent[K.unit][0]) : lds_off(&S.lent[K.ci]);      // entry table of this lane's component
+  K.wrow = K.l_ii ? lds_off(&S.slot[K.ci]) : lds_off(&S.lsink[K.ci]);        // where its bit histories are written (+ node)
+  K.wrow_mask = K.l_ii ? 15u : 0u;
+  K.isse_m = K.l_isse ? -1 : 0;
+  K.cshift = K.l_isse ? 6u : 16u;
+  K.pself = 0;                                           // prediction of a lane that is neither ICM nor ISSE (MATCH, CONST)
+  if (K.ci < SP::n && mycp->type == ZH_CONS) K.pself = ((int)mycp->arg[0] - 128) * 4;
+  K.vo_mix = kOob; K.mx_base = 0; K.mx_size1 = 0; K.mx_rate = 0;
+  if (SP::nmix) {                                        // the mixer kept in HBM: lane (g, k) owns weight k of the rows its group reads
+    const ZhComp &mc = M->comp[SP::mix_lane[0]];
+    K.mx_base = uni((uint32_t)mc.cm_off);
+    K.mx_size1 = uni(mc.cm_mask);
+    K.mx_rate = (int)uni((uint32_t)mc.arg[3]);
+    asm volatile("" : "+v"(K.mx_rate));
+    if (K.ci >= SP::mix_j0[0] && K.ci < SP::mix_j0[0] + SP::mix_m[0]) K.vo_mix = (K.ci - SP::mix_j0[0]) * 4u;
+  }
+  K.l_feed = K.vo_mix != kOob;
+  K.slot_mem = slot_mem;
+  K.rsrc = __builtin_amdgcn_make_buffer_rsrc(slot_mem, 0, (int)uni((uint32_t)M->arena_bytes), 0x00020000);
+}
+
+// Hash rows of a nibble (c8 == 1 or 16 <= c8 < 32), Predictor.find (Predictor.cs:550-567): see zh_chain2.hip
+struct NbProbe { v4u r0, r1, r2; uint32_t h0, chk; };
+template <class SP>
+__device__ __forceinline__ void nb_rows_issue(const NbK<SP> &K, const NbV &V, uint32_t c8, NbProbe &pr, bool on) {
+  const uint32_t cxt = V.hv + 16u * c8;
+  pr.chk = (cxt >> K.sizebits2) & 255;
+  pr.h0 = (cxt * 16u) & (K.ht_mask - 15u);
+  const uint32_t vo = (K.l_ii && on) ? K.hto + pr.h0 : kOob;
+  pr.r0 = __builtin_amdgcn_raw_buffer_load_b128(K.rsrc, vo, 0, 0);
+  pr.r1 = __builtin_amdgcn_raw_buffer_load_b128(K.rsrc, vo ^ 16u, 0, 0);
+  pr.r2 = __builtin_amdgcn_raw_buffer_load_b128(K.rsrc, vo ^ 32u, 0, 0);
+}
+// find on the three probes; rows this wave evicted after the probes' loads may have been issued (olda, old) are taken
+// from the copies.  Result: the row and its place (nothing is written).
+__device__ __forceinline__ void nb_rows_pick(const NbProbe &pr, const v4u &olda, uint32_t olda_off, bool olda_valid, const v4u &old, uint32_t old_off,
+                                             bool old_valid, v4u &row, uint32_t &sel) {
+  const uint32_t h0 = pr.h0, h1 = h0 ^ 16u, h2 = h0 ^ 32u;
+  v4u r0 = pr.r0, r1 = pr.r1, r2 = pr.r2;
+  if (olda_valid && olda_off == h0) r0 = olda;
+  if (olda_valid && olda_off == h1) r1 = olda;
+  if (olda_valid && olda_off == h2) r2 = olda;
+  if (old_valid && old_off == h0) r0 = old;
+  if (old_valid && old_off == h1) r1 = old;
+  if (old_valid && old_off == h2) r2 = old;
+  const uint32_t chk = pr.chk;
+  const bool m0 = (r0.x & 255) == chk, m1 = (r1.x & 255) == chk, m2 = (r2.x & 255) == chk;
+  const uint32_t p0 = (r0.x >> 8) & 255, p1 = (r1.x >> 8) & 255, p2 = (r2.x >> 8) & 255;
+  const uint32_t victim = (p0 <= p1 && p0 <= p2) ? h0 : p1 < p2 ? h1 : h2;
+  sel = m0 ? h0 : m1 ? h1 : m2 ? h2 : victim;
+  const v4u fresh = {chk, 0, 0, 0};
+  row = m0 ? r0 : m1 ? r1 : m2 ? r2 : fresh;
+}
+template <class SP>
+__device__ __forceinline__ void nb_row_take(const NbK<SP> &K, NbV &V, const v4u &row, uint32_t sel) {     // every lane holds the row of its component
+  V.rowoff = sel; V.rowvalid = 1u;
+  V.row_x = K.l_ii ? row.x : 0u; V.row_q1 = K.l_ii ? row.y : 0u; V.row_q2 = K.l_ii ? row.z : 0u; V.row_q3 = K.l_ii ? row.w : 0u;
+}
+// the row of the finished nibble: its content for the caller, and (row_store) its write-back, fire and forget.  The store is
+// issued BEHIND whatever loads the caller still has to take: vector memory completes in issue order (one vmcnt for loads and
+// stores), so a wait for anything issued after a store also waits for that store's acknowledgement
+template <class SP, class LDS>
+__device__ __forceinline__ void nb_row_old(const NbK<SP> &K, const NbV &V, LDS &S, v4u &old, uint32_t &old_off, uint32_t &old_valid) {
+  old = *(lds_u4_p)lds_off(&S.slot[K.ci]);
+  old_off = V.rowoff; old_valid = (V.rowvalid && K.l_ii) ? 1u : 0u;
+}
+template <class SP>
+__device__ __forceinline__ void nb_row_store(const NbK<SP> &K, const v4u &old, uint32_t old_off, uint32_t old_valid) {
+  __builtin_amdgcn_raw_buffer_store_b128(old, K.rsrc, (old_valid && K.canon) ? K.hto + old_off : kOob, 0, 0);
+}
+template <class SP>
+__device__ __forceinline__ void nb_mix_set(const NbK<SP> &K, NbV &V, uint32_t hq) {
+  V.mx_rb = K.vo_mix + (K.mx_base + __umul24(uni(hq) & K.mx_size1 & ~255u, NbK<SP>::mx_m4));
+}
+// rows of levels 2..4 of a nibble whose first row is c8n (1, or 16 + first nibble); level 1 comes staged / fetched ahead
+template <class SP>
+__device__ __forceinline__ void nb_mix_rows(const NbK<SP> &K, NbV &V, uint32_t c8n) {
+#pragma unroll
+  for (int dd = 1; dd <= 4; ++dd) V.mrowl[dd] = V.mx_rb + __umul24((c8n << (dd - 1)) + K.pre[dd], NbK<SP>::mx_m4);
+#pragma unroll
+  for (int dd = 2; dd <= 4; ++dd) V.mwl[dd] = (int)__builtin_amdgcn_raw_buffer_load_b32(K.rsrc, V.mrowl[dd], 0, 0);
+}
+template <class SP>
+__device__ __forceinline__ void nb_match_prefetch(const NbK<SP> &K, NbV &V) {
+  const uint32_t ml = (uint32_t)(SP::match_lane >= 0 ? SP::match_lane : 0);
+  const uint32_t msk = rdlane(K.ht_mask, ml), base = rdlane(K.hto, ml);
+  const uint32_t lim = (rdlane(V.m_limit, ml) + 1u) & msk;                 // m_limit once this byte is stored
+  const uint32_t off = lim - rdlane(V.cm_pre, ml);                        // the candidate's distance, should the byte end unmatched
+  V.va_pre = __builtin_amdgcn_raw_buffer_load_b8(K.rsrc, base + ((lim - K.lane - 1u) & msk), 0, 0);
+  V.vb_pre = __builtin_amdgcn_raw_buffer_load_b8(K.rsrc, base + ((lim - K.lane - off - 1u) & msk), 0, 0);
+  V.mbn_pre = __builtin_amdgcn_raw_buffer_load_b8(K.rsrc, K.l_match ? base + ((lim - off) & msk) : kOob, 0, 0);
+  V.mbc_pre = __builtin_amdgcn_raw_buffer_load_b8(K.rsrc, K.l_match ? base + ((lim - V.m_ptr) & msk) : kOob, 0, 0);
+}
+// Predictor.update's MATCH part at the byte boundary (Predictor.cs:391-410); c is already in the history and the
+// hash index, m_limit advanced
+template <class SP, class LDS>
+__device__ __forceinline__ void nb_match_boundary(const NbK<SP> &K, NbV &V, LDS &S, uint32_t cb) {
+  const uint32_t lane = K.lane;
+  const bool zero = V.m_len == 0;
+  const uint32_t nptr = V.m_limit - V.cm_pre;
+  const bool need = K.l_match && zero && (nptr & K.ht_mask) != 0;
+  V.m_ptr = (K.l_match && zero) ? nptr : V.m_ptr;
+  V.m_len = (K.l_match && !zero && V.m_len < 255) ? V.m_len + 1 : V.m_len;
+  if (__ballot(need) != 0) {                         // verify the candidate with the whole wave (Predictor.cs:403-405)
+    const uint32_t ml = (uint32_t)SP::match_lane;
+    const uint32_t lim = rdlane(V.m_limit, ml), off = rdlane(V.m_ptr, ml), msk = rdlane(K.ht_mask, ml);
+    const uint32_t a = lane == 0 ? cb : (V.va_pre & 255u);
+    const uint32_t b = ((lane + off) & msk) == 0 ? cb : (V.vb_pre & 255u);
+    uint64_t mism = __ballot(a != b);
+    uint32_t len = 64;
+    if (LIKELY(mism != 0)) len = (uint32_t)__builtin_ctzll(mism);
+    else {
+      const uint8_t *hp = K.slot_mem + rdlane(K.hto, ml);
+      for (uint32_t base = 64; base < 256; base += 64) {
+        const uint32_t t = base + lane;
+        const bool eq = t < 255 && hp[(lim - t - 1) & msk] == hp[(lim - t - off - 1) & msk];
+        mism = __ballot(!eq);
+        if (mism) { len += (uint32_t)__builtin_ctzll(mism); break; }
+        len += 64;
+      }
+    }
+    const uint32_t nl = len > 255 ? 255 : len;
+    V.m_len = K.l_match ? nl : V.m_len;
+    V.m_byte = K.l_match ? (((off - 1u) & msk) == 0 ? cb : (V.mbn_pre & 255u)) : V.m_byte;
+  } else {
+    const uint32_t cont = ((V.m_ptr - 1u) & K.ht_mask) == 0 ? cb : (V.mbc_pre & 255u);
+    V.m_byte = (K.l_match && V.m_len) ? cont : V.m_byte;
+  }
+  const uint32_t pw = *(lds_u32_p)(lds_off(S.pm01) + V.m_len * 4u);      // m_len stays 0 in the other lanes
+  V.pm0 = (int)(int16_t)(pw & 0xffffu); V.pm1 = (int)pw >> 16;
+}
+
+// Renormalisation when the coded bytes it can need are in the register-held chunk (the fast loop checks that before a byte):
+// Decoder.cs:148-156, scalar throughout.
+__device__ __forceinline__ void nb_renorm_fast(Dec &d, uint32_t cur, uint32_t &k) {
+  uint32_t low = d.low, high = d.high, curr = d.curr, kk = k;
+  do {
+    high = high << 8 | 255;
+    low = low << 8;
+    low = low ? low : 1u;
+    const uint32_t c = (rdlane(cur, kk >> 2) >> ((kk & 3) * 8)) & 255u;
+    ++kk;
+    curr = curr << 8 | c;
+  } while ((high ^ low) < 0x1000000u);
+  d.low = uni(low); d.high = uni(high); d.curr = uni(curr); k = uni(kk);
+}
+
+// ---- the eight bits of a byte (Decoder.cs:48-55 around Predictor.predict / update); j, bad, err as in zh_chain2.hip.
+// FAST: renormalisations take their bytes from the chunk in registers without the refill test (the caller made sure)
+template <class SP, bool PROF, bool FAST, class LDS>
+__device__ __forceinline__ uint32_t nb_decode_byte(const NbK<SP> &K, NbV &V, LDS &S, Dec &d, InBuf &in, uint32_t &j, uint32_t &bad, uint32_t &err,
+                                                   uint32_t bseq, NbProf &P) {
+  constexpr uint32_t NC = NbK<SP>::NC;
+  constexpr uint32_t mx_m4 = NbK<SP>::mx_m4;
+  const uint32_t lane = K.lane, ci = K.ci, g = K.g;
+  const lds_i16_p lds_stretch = (lds_i16_p)lds_off(S.stretch);
+  const lds_u16_p lds_squash = (lds_u16_p)lds_off(S.squash);
+  const uint32_t ns_off = lds_off(S.ns);
+  NB_STAMP(10);
+  int rnd12 = 1 << 12;                           // the weight updates' rounding addend, in a VGPR (zh_chain2.hip, C2V 64)
+  asm volatile("" : "+v"(rnd12));
+  // ---- the second nibble's hash rows, for the two values of the first nibble this group's prefix leaves open
+  // (16 candidates over the 8 groups), and the mixer weights of the rows they start with
+  NbProbe cand[2];
+  int cmw[2] = {0, 0};
+#pragma unroll
+  for (uint32_t k = 0; k < 2; ++k) {
+    nb_rows_issue(K, V, 16u + 2u * g + k, cand[k], K.act);
+    if (SP::nmix) cmw[k] = (int)__builtin_amdgcn_raw_buffer_load_b32(K.rsrc, K.act ? V.mx_rb + __umul24(16u + 2u * g + k, mx_m4) : kOob, 0, 0);
+  }
+  uint32_t cbyte = 0;
+  int p_l1 = 0, sqm_l1 = 0, mw_l1 = 0;            // mixer: level 1 of the first nibble (the same in every group)
+#pragma unroll
+  for (int nib = 0; nib < 2; ++nib) {
+    // ================= one nibble: four levels, every group on its own path =================
+    uint32_t st[5], ea[5], nsp[5], nA[5], nB[5], nsb[5];
+    v2u et[5];
+    int nmw[5] = {0, 0, 0, 0, 0};
+    st[1] = __builtin_amdgcn_ubfe(V.row_x, 8u, 8u);
+    st[2] = __builtin_amdgcn_ubfe(V.row_x, K.sh2, 8u);
+    st[3] = __builtin_amdgcn_ubfe(V.row_q1, K.sh3, 8u);
+    st[4] = __builtin_amdgcn_ubfe(K.b1 ? V.row_q3 : V.row_q2, K.sh4, 8u);
+#pragma unroll
+    for (int dd = 1; dd <= 4; ++dd) {
+      ea[dd] = K.tab + st[dd] * 8u;
+      et[dd] = *(lds_u2_p)ea[dd];
+      nsp[dd] = *(lds_u16_p)(ns_off + st[dd] * 4u);      // next(state, 0) | next(state, 1) << 8
+    }
+    // MATCH: the nibble the match predicts; a group whose path left it predicts 0 from there on
+    uint32_t ex = 0, mism = 0;
+    if (SP::match_lane >= 0) {
+      ex = (V.m_byte >> (nib ? 0u : 4u)) & 15u;
+      mism = (g ^ (ex >> 1)) & 7u;
+    }
+    uint32_t nv = 0;                               // the nibble's bits decoded so far (scalar)
+    int p = 0, sqp = 0, sqm = 0, pj = 0;
+    uint32_t eA = 0, eB = 0;
+#pragma unroll
+    for (int dd = 1; dd <= 4; ++dd) {
+      // ---- the entry of this level: from the table, or from a level of this path that trained the same entry
+      eA = et[dd].x; eB = et[dd].y;
+#pragma unroll
+      for (int k = 1; k < dd; ++k) {
+        const bool same = ea[dd] == ea[k];
+        eA = same ? nA[k] : eA;
+        eB = same ? nB[k] : eB;
+      }
+      // ---- predict (Predictor.cs:259-343)
+      int xs = K.pself;
+      if (SP::match_lane >= 0) {
+        const uint32_t cbit = (ex >> (4 - dd)) & 1u;
+        int pmv = cbit ? V.pm1 : V.pm0;
+        const uint32_t left = dd == 1 ? 0u : dd == 2 ? (mism & 4u) : dd == 3 ? (mism & 6u) : mism;
+        pmv = left ? 0 : pmv;
+        xs = K.l_match ? pmv : K.pself;
+      }
+      const int x = K.l_ii ? (int)eB : xs;
+      const int cw0 = (int)eA & K.isse_m;
+      const int cw1m = (int)((uint32_t)x << K.cshift);
+      p = x;
+#pragma unroll
+      for (uint32_t t = 0; t < SP::depth; ++t) p = med3i((__mul24(shr1(p), cw0) + cw1m) >> 16, -2048, 2047);
+      uint32_t psv;
+      if (SP::nmix) {
+        const int term = sum8(__mul24(V.mwl[dd] >> 8, p));     // lanes that do not feed the mixer hold weight 0
+        const int pmx = med3i(term >> 8, -2048, 2047);
+        if (ci == SP::mix_lane[0]) p = pmx;
+        sqm = (int)*(lds_u16_p)((uint32_t)(uintptr_t)lds_squash + (uint32_t)(pmx + 2048) * 2u);
+      }
+      sqp = (int)*(lds_u16_p)((uint32_t)(uintptr_t)lds_squash + (uint32_t)(p + 2048) * 2u);
+      // ---- the part of the update that needs neither the squashed prediction nor the decoded bit: the ICM's entry
+      // (levels 1-3: the group's own bit; Predictor.cs:375-381) — its stretch look-up travels under the squash look-up
+      const uint32_t yl_pre = dd < 4 ? K.ybit[dd] : 0u;
+      const int ey_pre = yl_pre ? 32767 : 0;
+      uint32_t ncm = eA + (uint32_t)((int)(ey_pre - (int)(eA >> 8)) >> 2);
+      int npst = 0;
+      if (dd < 4) npst = *(lds_i16_p)((uint32_t)(uintptr_t)lds_stretch + ((ncm >> 7) & 0x1fffeu));
+      psv = ((uint32_t)(SP::nmix ? sqm : sqp) << 17) | 0x10000u;
+      if (SP::nmix && nib == 0 && dd == 1) { p_l1 = p; sqm_l1 = sqm; mw_l1 = V.mwl[1]; }
+      asm("" : "+v"(psv));
+      pj = shr1(p);                              // ISSE update: the prediction of the component before
+      // ---- decode (Decoder.cs:136-158): the split factor of the group the decoded bits lead to
+      const uint32_t lsel = (nv << (4 - dd)) * NC + SP::final_lane;
+      const uint32_t ps = rdlane(psv, lsel);
+      uint32_t jb = uni(j), xr;
+      d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr);   // (already scalar: says so to the compiler)
+      ZH_DEC_STEP_LITE(d, ps, jb, xr);
+      j = jb;
+      if (UNLIKELY(xr < 0x1000000u)) {
+        if (FAST) {
+          nb_renorm_fast(d, in.cur, in.k);
+          const uint32_t oor = (uint32_t)(d.curr < d.low) | (uint32_t)(d.curr > d.high);
+          if (!(nib == 1 && dd == 4)) bad = uni(bad | oor);    // after the byte's last bit the next EOS step re-checks by itself
+        } else {
+          const uint32_t was = bad;
+          uint32_t later = 0;
+          if (dec_renorm_chk(d, in, lane, (nib == 1 && dd == 4) ? later : bad) && !err) err = was ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF;
+        }
+      }
+      const uint32_t y = uni(j & 1u);
+      nv = nv * 2u + y;
+      // ---- update (Predictor.cs:363-461): levels 1-3 with the group's own bit, level 4 with the decoded one
+      const uint32_t yl = dd < 4 ? K.ybit[dd] : y;
+      const int ey = yl ? 32767 : 0;
+      const int e = ey - sqp;
+      nsb[dd] = __builtin_amdgcn_ubfe(nsp[dd], yl * 8u, 8u);
+      if (dd == 4) {
+        ncm = eA + (uint32_t)((int)(ey - (int)(eA >> 8)) >> 2);
+        npst = *(lds_i16_p)((uint32_t)(uintptr_t)lds_stretch + ((ncm >> 7) & 0x1fffeu));
+      }
+      const int nw0 = med3i((int)eA + ((__mul24(e, pj) + rnd12) >> 13), -(1 << 19), (1 << 19) - 1);
+      const int nw1 = med3i((int)eB + ((e + 16) >> 5), -(1 << 19), (1 << 19) - 1);
+      nA[dd] = K.l_isse ? (uint32_t)nw0 : ncm;
+      nB[dd] = K.l_isse ? (uint32_t)nw1 : (uint32_t)npst;
+      if (SP::nmix) {                            // MIX (Predictor.cs:427-439)
+        const int eq = __mul24(ey - sqm, K.mx_rate) >> 4;
+        nmw[dd] = med3i(V.mwl[dd] + ((__mul24(eq, p) + rnd12) >> 13), -(1 << 19), (1 << 19) - 1);
+      }
+    }
+    NB_STAMP(nib);
+    // ---- commit: the group the nibble's first three bits name
+    const uint32_t gw = nv >> 1;
+    if (K.act && g == gw) {
+#pragma unroll
+      for (int dd = 1; dd <= 4; ++dd) *(lds_u2_p)ea[dd] = v2u{nA[dd], nB[dd]};
+#pragma unroll
+      for (int dd = 1; dd <= 4; ++dd) *(lds_u8_p)(K.wrow + (K.node[dd] & K.wrow_mask)) = (uint8_t)nsb[dd];
+    }
+    if (SP::nmix) {
+#pragma unroll
+      for (int dd = 1; dd <= 4; ++dd) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw[dd], K.rsrc, (K.act && g == gw) ? V.mrowl[dd] : kOob, 0, 0);
+    }
+    if (SP::nmix && nib == 0) {
+      // row c8 = 1 of this byte's block as it is now, in every group (level 1 is the same everywhere; y1 is known): should
+      // the next byte have the same mixer context, the helper's copy of that row may predate the store above
+      const int eq1 = __mul24(((nv & 8u) ? 32767 : 0) - sqm_l1, K.mx_rate) >> 4;
+      V.w1_new = med3i(mw_l1 + ((__mul24(eq1, p_l1) + rnd12) >> 13), -(1 << 19), (1 << 19) - 1);
+    }
+    if (SP::match_lane >= 0) {                    // MATCH (Predictor.cs:383-384): a miss ends the match
+      const bool miss = nv != ex;
+      V.m_len = miss ? 0u : V.m_len; V.pm0 = miss ? 0 : V.pm0; V.pm1 = miss ? 0 : V.pm1;
+    }
+    NB_STAMP(2 + nib);
+    if (nib == 0) {
+      // ---- second nibble (Predictor.cs:267-270: c8 & 0xf0 == 16): its rows were requested when the byte began
+      cbyte = nv;
+      v4u old; uint32_t old_off, old_valid;
+      nb_row_old(K, V, S, old, old_off, old_valid);
+      V.old1 = old; V.old1_off = old_off; V.old1_valid = old_valid;
+      if (SP::nmix > 0) c2_put0(&S.mb_nib, bseq << 8 | (nv & 15u));       // (see zh_chain2.hip for what the helper's loads must see)
+      const bool k1 = (nv & 1u) != 0;
+      NbProbe pr;
+      pr.h0 = k1 ? cand[1].h0 : cand[0].h0; pr.chk = k1 ? cand[1].chk : cand[0].chk;
+      pr.r0 = k1 ? cand[1].r0 : cand[0].r0; pr.r1 = k1 ? cand[1].r1 : cand[0].r1; pr.r2 = k1 ? cand[1].r2 : cand[0].r2;
+      v4u row; uint32_t sel;
+      nb_rows_pick(pr, V.oldb, V.oldb_off, V.oldb_valid != 0, old, old_off, old_valid != 0, row, sel);   // (oldb: written back just before the candidates were requested)
+      asm volatile("" :: "v"(row.x), "v"(row.y), "v"(row.z), "v"(row.w), "v"(sel));       // (the candidates' loads are consumed: now the store)
+      nb_row_store(K, old, old_off, old_valid);
+      if (K.act && g == gw) {
+        *(lds_u4_p)lds_off(&S.slot[ci]) = row;
+        S.slotoff[ci] = sel;
+        if (SP::nmix) S.mixb[ci] = (uint32_t)(k1 ? cmw[1] : cmw[0]);
+      }
+      asm volatile("" ::: "memory");
+      {
+        const v4u rowb = *(lds_u4_p)lds_off(&S.slot[ci]);
+        const uint32_t selb = S.slotoff[ci];
+        nb_row_take(K, V, rowb, selb);
+        if (SP::nmix) { V.mwl[1] = K.l_feed ? (int)S.mixb[ci] : 0; nb_mix_rows(K, V, 16u + nv); }
+      }
+      if (SP::nmix == 0) c2_put0(&S.mb_nib, bseq << 8 | (nv & 15u));      // min: after the rows requested at the byte's start were consumed
+      if (SP::match_lane >= 0) nb_match_prefetch(K, V);
+      NB_STAMP(4);
+    } else cbyte = cbyte * 16u + nv;
+  }
+  return cbyte;
+}
+
+// ---- byte boundary: MATCH (Predictor.cs:391-410), h[] and the rows of the next byte from the helper wave.
+// false: the helper wavefront stopped answering (cannot happen by design)
+template <class SP, bool PROF, class LDS>
+__device__ __forceinline__ bool nb_boundary(const NbK<SP> &K, NbV &V, LDS &S, int c, uint32_t &bseq, bool &helper_ok, NbProf &P) {
+  const uint32_t ci = K.ci;
+  v4u sg_row = {0, 0, 0, 0}; uint32_t sg_sel = 0; int sg_mw = 0;
+  if (SP::match_lane >= 0) {                   // still with the h[i] of the byte just coded (update0 runs before z.run)
+    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)c, K.rsrc, (K.l_match && K.canon) ? K.hto + (V.m_limit & K.ht_mask) : kOob, 0, 0);
+    V.m_limit = K.l_match ? (V.m_limit + 1) & K.ht_mask : V.m_limit;
+    __builtin_amdgcn_raw_buffer_store_b32(V.m_limit, K.rsrc, (K.l_match && K.canon) ? K.cmo + (V.hv & K.cm_mask) * 4u : kOob, 0, 0);   // (its old value: cm_pre)
+  }
+  c2_put0(&S.mb_byte, bseq << 8 | (uint32_t)c);
+  NB_STAMP(5);
+  const uint32_t lo = (uint32_t)c & 15u, un_ = K.un_;
+  auto read_staged = [&]() __attribute__((always_inline)) {
+    V.hv = S.hspec[ci & ((1u << SP::hh) - 1u)][lo];
+    sg_row = *(lds_u4_p)lds_off(&S.selrow[un_][lo]); sg_sel = S.seloff[un_][lo];
+    if (SP::nmix) { const uint32_t jj = ci - SP::mix_j0[0]; sg_mw = (int)S.mixst[0][lo][jj & 15u]; }
+  };
+  {
+    const uint32_t rdy_v = __hip_atomic_load(&S.mb_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");             // (the flag first: what is read behind it is what the flag vouches for)
+    read_staged();
+    if (UNLIKELY(uni(rdy_v) != uni(bseq))) {   // not yet: wait, then read again
+      if (helper_ok) helper_ok = c2_wait(&S.mb_ready, bseq);
+      asm volatile("" ::: "memory");
+      read_staged();
+    }
+  }
+  if (!helper_ok) return false;
+  ++bseq;
+  NB_STAMP(6);
+  v4u old; uint32_t old_off, old_valid;
+  nb_row_old(K, V, S, old, old_off, old_valid);
+  nb_row_store(K, old, old_off, old_valid);
+  NbProbe pr;
+  {
+    const uint32_t cxt = V.hv + 16u;
+    pr.chk = (cxt >> K.sizebits2) & 255;
+    pr.h0 = (cxt * 16u) & (K.ht_mask - 15u);
+  }
+  if (SP::nmix) {
+    const uint32_t rb_was = V.mx_rb;
+    nb_mix_set(K, V, rdlane(V.hv, SP::mix_lane[0]));
+    V.mwl[1] = K.l_feed ? (V.mx_rb == rb_was ? V.w1_new : sg_mw) : 0;
+    nb_mix_rows(K, V, 1u);
+  }
+  if (SP::match_lane >= 0) {
+    nb_match_boundary(K, V, S, (uint32_t)c);
+    V.cm_pre = __builtin_amdgcn_raw_buffer_load_b32(K.rsrc, K.l_match ? K.cmo + (V.hv & K.cm_mask) * 4u : kOob, 0, 0);
+  }
+  const bool near = (V.old1_valid && ((V.old1_off ^ pr.h0) & ~48u) == 0) || (old_valid && ((old_off ^ pr.h0) & ~48u) == 0);
+  v4u row = sg_row; uint32_t sel = sg_sel;
+  if (UNLIKELY(__ballot(near) != 0)) {         // something this wave wrote late lies in a probed bucket: the probes, patched
+    pr.r0 = *(lds_u4_p)lds_off(&S.rowst[un_][0][lo]);
+    pr.r1 = *(lds_u4_p)lds_off(&S.rowst[un_][1][lo]);
+    pr.r2 = *(lds_u4_p)lds_off(&S.rowst[un_][2][lo]);
+    nb_rows_pick(pr, V.old1, V.old1_off, V.old1_valid != 0, old, old_off, old_valid != 0, row, sel);
+  }
+  if (K.canon) *(lds_u4_p)lds_off(&S.slot[ci]) = row;
+  nb_row_take(K, V, row, sel);
+  V.oldb = old; V.oldb_off = old_off; V.oldb_valid = old_valid;
+  asm volatile("" ::: "memory");
+  NB_STAMP(7);
+  return true;
+}
+
+// ---- The common case as a function of its own: post-processor in PASS state, nothing unusual in the byte.  It is a real call
+// (noinline) so that its loop is compiled for itself: inside decode_nibble_body the general form's many live values and exits
+// made the compiler carry the decoder state in vector registers and run the loop's control flow through exec masks.
+// State crosses in LDS (S.fxs: scalars, S.fxv: per-lane words).  Leaves when a byte cannot start here: fxs[kFxWhy]
+//   0  nothing done for the next byte (priming, < 40 coded bytes in the chunk, output capacity reached)
+//   1  the EOS flag's step is done and something about it is unusual (fxs[kFxJ], kFxBad, kFxRn hold its results)
+//   2  error (fxs[kFxStatus])
+enum : int { kFxLow = 0, kFxHigh, kFxCurr, kFxK, kFxAvail, kFxBseq, kFxHelper, kFxWhy, kFxJ, kFxBad, kFxRn, kFxStatus, kFxModel, kFxWord, kFxRoom,
+             kFxLenLo, kFxLenHi, kFxStoredLo, kFxStoredHi, kFxCapLo, kFxCapHi, kFxBaseLo, kFxBaseHi, kFxProf, kFxN = kFxProf + 36 };
+template <class SP, bool PROF, class LDS>
+__device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_) {
+  // (arguments of a real call arrive in vector registers: say that they are the same in every lane, or every buffer access
+  // below is wrapped in a loop over the distinct resources the lanes might hold)
+  // (the block's LDS struct: the low half of the generic pointer is its LDS address; going through an LDS-typed pointer lets the
+  // compiler see that every access below is an LDS access)
+  typedef __attribute__((address_space(3))) LDS *lds_S_p;
+  LDS &S = *(LDS *)(lds_S_p)(uintptr_t)uni((uint32_t)(uintptr_t)Sp_);
+  const ZhLaunch &L = *reinterpret_cast<const ZhLaunch *>(uni64((uint64_t)(uintptr_t)Lp_));
+  const uint32_t lane = threadIdx.x & 63u;
+  NbK<SP> K;
+  uint8_t *slot_mem = reinterpret_cast<uint8_t *>(uni64((uint64_t)(uintptr_t)(L.arena + (uint64_t)blockIdx.x * L.arena_stride)));
+  nb_setup(K, S, &L.models[uni(S.fxs[kFxModel])], slot_mem, lane);
+  NbV V;
+  {
+    uint32_t *w = reinterpret_cast<uint32_t *>(&V);
+#pragma unroll
+    for (int i = 0; i < kNbVWords; ++i) w[i] = S.fxv[i][lane];
+  }
+  NbProf P;
+  if (PROF) { for (int i = 0; i < 16; ++i) P.prof[i] = 0; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(P.tprev)::"memory"); }
+  Dec d;
+  d.low = uni(S.fxs[kFxLow]); d.high = uni(S.fxs[kFxHigh]); d.curr = uni(S.fxs[kFxCurr]);
+  InBuf in;
+  in.stream = L.in; in.total = L.in_total; in.cbase = 0;
+  in.k = uni(S.fxs[kFxK]); in.avail = uni(S.fxs[kFxAvail]); in.cur = S.fxv[kNbVWords][lane];
+  OutBuf ob;
+  ob.base = reinterpret_cast<uint8_t *>((uint64_t)uni(S.fxs[kFxBaseLo]) | (uint64_t)uni(S.fxs[kFxBaseHi]) << 32);
+  ob.cap = (uint64_t)uni(S.fxs[kFxCapLo]) | (uint64_t)uni(S.fxs[kFxCapHi]) << 32;
+  ob.len = (uint64_t)uni(S.fxs[kFxLenLo]) | (uint64_t)uni(S.fxs[kFxLenHi]) << 32;
+  ob.stored = (uint64_t)uni(S.fxs[kFxStoredLo]) | (uint64_t)uni(S.fxs[kFxStoredHi]) << 32;
+  ob.word = uni(S.fxs[kFxWord]); ob.room = uni(S.fxs[kFxRoom]); ob.park = S.fxv[kNbVWords + 1][lane];
+  uint32_t bseq = uni(S.fxs[kFxBseq]);
+  bool helper_ok = true;
+  uint32_t why = 0, j = 0, bad = 0, rn = 0, status = 0;
+  const uint32_t klim = in.avail >= 40u ? in.avail - 40u : 0u;
+  uint32_t vlo = (uint32_t)(uintptr_t)ob.base + (uint32_t)ob.len;     // low bits of the virtual output position
+  uint32_t nput = 0, room = ob.room, word = ob.word;
+  if constexpr (SP::id == 1 && !PROF && ZH_NB_ASM != 0) {
+    // ---- the loop in assembly (zh_nb_fast.h, tools/gen_nb_asm.py): constants and state through LDS
+    if (lds_off(S.stretch) == 0 && V.rowvalid) {
+      const uint32_t hmask_ = (1u << SP::hh) - 1u;
+      uint32_t kc[kNbK_count];
+      kc[kNbK_tab] = K.tab; kc[kNbK_slot] = K.wrow; kc[kNbK_wr2] = K.wrow + K.node[2]; kc[kNbK_wr3] = K.wrow + K.node[3]; kc[kNbK_wr4] = K.wrow + K.node[4];
+      kc[kNbK_sh2] = K.sh2; kc[kNbK_sh3] = K.sh3; kc[kNbK_sh4] = K.sh4;
+      kc[kNbK_ey1] = K.ybit[1] ? 32767u : 0u; kc[kNbK_ey2] = K.ybit[2] ? 32767u : 0u; kc[kNbK_ey3] = K.ybit[3] ? 32767u : 0u;
+      kc[kNbK_ys1] = K.ybit[1] * 8u; kc[kNbK_ys2] = K.ybit[2] * 8u; kc[kNbK_ys3] = K.ybit[3] * 8u;
+      kc[kNbK_hto] = K.hto; kc[kNbK_htm15] = K.ht_mask - 15u; kc[kNbK_sb2] = K.sizebits2; kc[kNbK_cshift] = K.cshift; kc[kNbK_issem] = (uint32_t)K.isse_m;
+      kc[kNbK_c8off] = 256u + 32u * K.g; kc[kNbK_g] = K.g;
+      kc[kNbK_selrow] = lds_off(&S.selrow[K.un_][0]); kc[kNbK_seloff] = lds_off(&S.seloff[K.un_][0]);
+      kc[kNbK_hspec] = lds_off(&S.hspec[K.ci & hmask_][0]); kc[kNbK_rowst] = lds_off(&S.rowst[K.un_][0][0]); kc[kNbK_slotoff] = lds_off(&S.slotoff[K.ci]);
+      kc[kNbK_koob] = kOob; kc[kNbK_c2047] = 2047u; kc[kNbK_c512k] = (1u << 19) - 1u; kc[kNbK_rnd] = 1u << 12; kc[kNbK_c10000] = 0x10000u;
+      kc[kNbK_evo] = K.canon ? K.hto : kOob; kc[kNbK_mb] = lds_off(&S.mb_nib);
+#pragma unroll
+      for (int i = 0; i < kNbK_count; ++i) S.fxk[i][lane] = kc[i];
+      S.fxa[kNbS_rx][lane] = V.row_x; S.fxa[kNbS_rq1][lane] = V.row_q1; S.fxa[kNbS_rq2][lane] = V.row_q2; S.fxa[kNbS_rq3][lane] = V.row_q3;
+      S.fxa[kNbS_rowoff][lane] = V.rowoff; S.fxa[kNbS_hv][lane] = V.hv;
+      S.fxa[kNbS_ob0][lane] = V.oldb.x; S.fxa[kNbS_ob1][lane] = V.oldb.y; S.fxa[kNbS_ob2][lane] = V.oldb.z; S.fxa[kNbS_ob3][lane] = V.oldb.w;
+      S.fxa[kNbS_oboff][lane] = V.oldb_valid ? V.oldb_off : 0xFFFFFFFFu;       // (no row written back yet: a place no bucket has)
+      S.fxa[kNbS_cur][lane] = in.cur;
+      const uint64_t sm = (uint64_t)(uintptr_t)slot_mem;
+      const v4u rs = {uni((uint32_t)sm), uni((uint32_t)(sm >> 32) & 0xffffu), uni((uint32_t)L.models[uni(S.fxs[kFxModel])].arena_bytes), 0x00020000u};
+      const uint32_t kb = lds_off(&S.fxk[0][lane]), vb = lds_off(&S.fxa[0][lane]);
+      const uint32_t sqb = uni(lds_off(S.squash) + 4096u), nsb = uni(lds_off(S.ns));
+      uint32_t lo_ = uni(d.low), hi_ = uni(d.high), cu_ = uni(d.curr), k_ = uni(in.k), asm_why = 0, obad = 0, ofail = 0, m0s = 0;
+      const uint32_t klim_s = uni(klim);
+      bseq = uni(bseq); nput = uni(nput); room = uni(room); word = uni(word);
+      for (;;) {
+        S.fxa[kNbS_park][lane] = ob.park;
+        const uint32_t vlo_s = uni(vlo);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ZH_NB_FAST_MIN_LOOP(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb);
+        ob.park = S.fxa[kNbS_park][lane];
+        if (asm_why != 3) break;
+        ob.len += nput; ob.word = word; ob.room = room; vlo += nput; nput = 0;      // the parked 256-byte chunk is complete
+        out_flush(ob, lane);
+        room = uni(ob.room);
+      }
+      d.low = uni(lo_); d.high = uni(hi_); d.curr = uni(cu_); in.k = uni(k_);
+      V.row_x = S.fxa[kNbS_rx][lane]; V.row_q1 = S.fxa[kNbS_rq1][lane]; V.row_q2 = S.fxa[kNbS_rq2][lane]; V.row_q3 = S.fxa[kNbS_rq3][lane];
+      V.rowoff = S.fxa[kNbS_rowoff][lane]; V.hv = S.fxa[kNbS_hv][lane];
+      V.oldb.x = S.fxa[kNbS_ob0][lane]; V.oldb.y = S.fxa[kNbS_ob1][lane]; V.oldb.z = S.fxa[kNbS_ob2][lane]; V.oldb.w = S.fxa[kNbS_ob3][lane];
+      { const uint32_t oo = S.fxa[kNbS_oboff][lane]; V.oldb_valid = oo != 0xFFFFFFFFu; V.oldb_off = oo; }
+      if (asm_why == 2) { why = 2; status = ofail ? (uint32_t)-24 : (uint32_t)ZH_E_CORRUPT; }
+    }
+  } else
+  for (;;) {
+    NB_STAMP(11);
+    d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr); in.k = uni(in.k);
+    if (UNLIKELY(d.curr == 0 || in.k > klim || room == 0 || in.avail < 40u)) break;
+    bad = 0; j = 0;
+    NB_STAMP(12);
+    ZH_DEC_STEP(d, 0u, j, bad, rn);              // EOS flag: p = 0
+    if (UNLIKELY((bad | rn | j) != 0)) { why = 1; break; }
+    uint32_t err = 0;
+    const uint32_t cb = uni(nb_decode_byte<SP, PROF, true>(K, V, S, d, in, j, bad, err, bseq, P));
+    if (UNLIKELY(bad != 0)) { why = 2; status = (uint32_t)ZH_E_CORRUPT; break; }
+    if (UNLIKELY((!nb_boundary<SP, PROF>(K, V, S, (int)cb, bseq, helper_ok, P)))) { why = 2; status = (uint32_t)-24; break; }     // ZPAQHIP_E_HIP
+    // ---- PostProcessor.write in PASS state: ZPAQL.outc (ZPAQL.cs:201-207), the dword assembled on the scalar unit
+    {
+      const uint32_t v = vlo + nput;
+      ++nput; --room;
+      const uint32_t sh = (v & 3u) * 8u;
+      word = sh ? (word | cb << sh) : cb;
+      if ((v & 3u) == 3u) {
+        ob.park = wrlane(word, (v >> 2) & 63u, ob.park);
+        if (UNLIKELY((v & 255u) == 255u)) {
+          ob.len += nput; ob.word = word; vlo += nput; nput = 0;
+          out_flush(ob, lane);
+          room = ob.room;
+        }
+      }
+    }
+    NB_STAMP(9);
+  }
+  ob.len += nput; ob.word = word; ob.room = room;
+  {
+    uint32_t *w = reinterpret_cast<uint32_t *>(&V);
+#pragma unroll
+    for (int i = 0; i < kNbVWords; ++i) S.fxv[i][lane] = w[i];
+    S.fxv[kNbVWords][lane] = in.cur;
+    S.fxv[kNbVWords + 1][lane] = ob.park;
+  }
+  if (lane == 0) {
+    S.fxs[kFxLow] = d.low; S.fxs[kFxHigh] = d.high; S.fxs[kFxCurr] = d.curr; S.fxs[kFxK] = in.k; S.fxs[kFxBseq] = bseq;
+    S.fxs[kFxWhy] = why; S.fxs[kFxJ] = j; S.fxs[kFxBad] = bad; S.fxs[kFxRn] = rn; S.fxs[kFxStatus] = status;
+    S.fxs[kFxWord] = ob.word; S.fxs[kFxRoom] = ob.room;
+    S.fxs[kFxLenLo] = (uint32_t)ob.len; S.fxs[kFxLenHi] = (uint32_t)(ob.len >> 32);
+    S.fxs[kFxStoredLo] = (uint32_t)ob.stored; S.fxs[kFxStoredHi] = (uint32_t)(ob.stored >> 32);
+    if (PROF) for (int i = 0; i < 16; ++i) { S.fxs[kFxProf + 2 * i] = (uint32_t)P.prof[i]; S.fxs[kFxProf + 2 * i + 1] = (uint32_t)(P.prof[i] >> 32); }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 template <class SP, bool PROF, class LDS>
 __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
-  constexpr uint32_t NC = SP::id == 1 ? 2u : 8u;          // lanes of a group
-  constexpr uint32_t NG = 8u;                               // groups: the 3-bit prefixes of a nibble's path
-  constexpr uint64_t kII = SP::icm | SP::isse;
-  static_assert(SP::n <= NC && NC * NG <= 64, "lane budget");
-  uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  uint64_t tprev = 0;
+  constexpr uint64_t kII = NbK<SP>::kII;
+  static_assert(SP::n <= NbK<SP>::NC && NbK<SP>::NC * NbK<SP>::NG <= 64, "lane budget");
+  NbProf P;
+  for (int i = 0; i < 16; ++i) P.prof[i] = 0;
+  P.tprev = 0;
   const uint32_t lane = threadIdx.x & 63u;
   const bool wave_a = (threadIdx.x >> 6) == 0;
-  const uint32_t ci = lane & (NC - 1u), g = (lane / NC) & (NG - 1u);
-  const bool act = lane < NC * NG;                         // min: lanes 16-63 repeat lanes 0-15 and never write
-  const uint32_t b1 = (g >> 2) & 1u, b2 = (g >> 1) & 1u, b3 = g & 1u;
-  const bool l_isse = (SP::isse >> ci) & 1, l_ii = (kII >> ci) & 1;
-  const bool l_match = SP::match_lane >= 0 && ci == (uint32_t)SP::match_lane;
 
   if (wave_a) {  // model-independent tables -> LDS
     const ZhTables *T = L.tables;
@@ -131,17 +752,6 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
   nb_wave_sync();
 
   uint8_t *slot_mem = L.arena + (uint64_t)blockIdx.x * L.arena_stride;
-  const lds_i16_p lds_stretch = (lds_i16_p)lds_off(S.stretch);
-  const lds_u16_p lds_squash = (lds_u16_p)lds_off(S.squash);
-  const uint32_t ns_off = lds_off(S.ns);
-
-  // ---- per-lane constants of the path this lane's group walks
-  const uint32_t sh2 = 16u + 8u * b1;                   // node 2 + b1: byte 2 / 3 of row dword 0
-  const uint32_t sh3 = 8u * (2u * b1 + b2);             // node 4 + 2 b1 + b2: a byte of dword 1
-  const uint32_t sh4 = 8u * (2u * b2 + b3);             // node 8 + 4 b1 + 2 b2 + b3: a byte of dword 2 (b1 = 0) / 3
-  const uint32_t node[5] = {0u, 1u, 2u + b1, 4u + 2u * b1 + b2, 8u + 4u * b1 + 2u * b2 + b3};
-  const uint32_t pre[5] = {0u, 0u, b1, 2u * b1 + b2, 4u * b1 + 2u * b2 + b3};      // c8 of level d = (c8 of the nibble << (d-1)) + pre[d]
-  const uint32_t ybit[4] = {0u, b1, b2, b3};             // the bit this group assumes at level d (d = 1..3)
 
   for (;;) {
     uint32_t bi = 0;
@@ -155,8 +765,6 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
     const uint64_t b_out_off = uni64(bdp->out_off), b_out_cap = uni64(bdp->out_cap);
     const ZhModel *M = &L.models[model_i];
     const uint32_t hh = uni(M->hh), hmb = uni(M->hm);
-    const uint32_t arena_bytes = uni((uint32_t)M->arena_bytes);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slot_mem, 0, (int)arena_bytes, 0x00020000);
 
     // ---- Predictor.init (Predictor.cs:82-171): the arena tables this kernel keeps in HBM
     for (uint32_t i = 0; i < SP::n; ++i) {
@@ -184,7 +792,6 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
       for (uint32_t i = lane; i < kPMBytes / 4; i += 64) reinterpret_cast<uint32_t *>(S.pmreg)[i] = 0;
     }
     // ---- ICM / ISSE entry tables in LDS.  Unit u of S.ent belongs to the u-th ICM/ISSE component.
-    const uint32_t unit = (uint32_t)__builtin_popcountll(kII & ((1ull << ci) - 1));
     {
       for (uint32_t j = lane; j < 256; j += 64) {
         const uint32_t n0 = S.ns[j * 4 + 2], n1 = S.ns[j * 4 + 3];
@@ -203,34 +810,10 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
     }
     nb_wave_sync();
 
-    // ---- per-lane constants of the component
-    const ZhComp *mycp = &M->comp[ci < SP::n ? ci : 0];
-    const uint32_t hto = l_ii || l_match ? (uint32_t)mycp->ht_off : 0u, ht_mask = mycp->ht_mask;
-    const uint32_t cmo = (uint32_t)mycp->cm_off, cm_mask = mycp->cm_mask;
-    const uint32_t sizebits2 = (uint32_t)mycp->arg[0] + 2;
-    const uint32_t tab = l_ii ? lds_off(&S.ent[unit][0]) : lds_off(&S.lent[ci]);      // entry table of this lane's component
-    const uint32_t wrow = l_ii ? lds_off(&S.slot[ci]) : lds_off(&S.lsink[ci]);        // where its bit histories are written (+ node)
-    const uint32_t wrow_mask = l_ii ? 15u : 0u;
-    const int isse_m = l_isse ? -1 : 0;
-    const uint32_t cshift = l_isse ? 6u : 16u;
-    int pself = 0;                                       // prediction of a lane that is neither ICM nor ISSE (MATCH, CONST)
-    if (ci < SP::n && mycp->type == ZH_CONS) pself = ((int)mycp->arg[0] - 128) * 4;
-    if (l_match && lane == (uint32_t)SP::match_lane) (slot_mem + hto)[0] = 1;           // Predictor.cs:121 ht(0)=1 ... overwritten like the reference
-
-    // the mixer kept in HBM: lane (g, k) owns weight k of the rows its group reads
-    uint32_t vo_mix = kOob;
-    uint32_t mx_base = 0, mx_size1 = 0;
-    int mx_rate = 0;
-    constexpr uint32_t mx_m4 = SP::mix_m[0] * 4u;
-    if (SP::nmix) {
-      const ZhComp &mc = M->comp[SP::mix_lane[0]];
-      mx_base = uni((uint32_t)mc.cm_off);
-      mx_size1 = uni(mc.cm_mask);
-      mx_rate = (int)uni((uint32_t)mc.arg[3]);
-      asm volatile("" : "+v"(mx_rate));
-      if (ci >= SP::mix_j0[0] && ci < SP::mix_j0[0] + SP::mix_m[0]) vo_mix = (ci - SP::mix_j0[0]) * 4u;
-    }
-    const bool l_feed = vo_mix != kOob;
+    NbK<SP> K;
+    nb_setup(K, S, M, slot_mem, lane);
+    if (K.l_match && lane == (uint32_t)SP::match_lane) (slot_mem + K.hto)[0] = 1;      // Predictor.cs:121 ht(0)=1 ... overwritten like the reference
+    const uint32_t ci = K.ci;
 
     // HCOMP machine (ZPAQL.cs:1010-1026): H and M in LDS; the helper wave runs the program
     Vm &hz = S.hz;
@@ -271,124 +854,17 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
       c2_put0(&S.mb_cmd, cmd_seq << 2 | kC2New);
       helper_ok = c2_wait(&S.mb_ack, cmd_seq << 2 | kC2New);
     }
-    if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
+    if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(P.tprev)::"memory"); }
     InBuf in;
     in.stream = L.in; in.total = L.in_total; in.cbase = 0; in.k = 0; in.avail = 0; in.cur = 0;
 
-    // ---- state carried from nibble to nibble (the same in every group)
-    uint32_t hv = 0;                                    // h[component] (Predictor.cs:469)
-    uint32_t rowoff = 0;                                // place of the hash row of the current nibble (in S.slot[ci] and below)
-    uint32_t row_x = 0, row_q1 = 0, row_q2 = 0, row_q3 = 0;   // the row as it was when the nibble began (zero for components without a table)
-    bool rowvalid = false;
-    int mwl[5] = {0, 0, 0, 0, 0};                       // mixer: this lane's weight in the row of level d of the current nibble
-    uint32_t mrowl[5] = {0, 0, 0, 0, 0};                // ... and its buffer offset
-    uint32_t mx_rb = kOob;                              // this lane's buffer offset in row 0 of the byte's block of mixer rows
-    // MATCH (Predictor.cs:273-287, 382-411): the Component fields, the same in every lane that stands for it
-    uint32_t m_len = 0, m_ptr = 0, m_limit = 0, m_byte = 0;
-    int pm0 = 0, pm1 = 0;                               // stretch of -+dt2k[len] for this byte; 0 once the match has failed
-    uint32_t cm_pre = 0, va_pre = 0, vb_pre = 0, mbn_pre = 0, mbc_pre = 0;      // see zh_chain2.hip
-    v4u oldb = {0, 0, 0, 0}; uint32_t oldb_off = 0; bool oldb_valid = false;    // the row written back at the last byte boundary
-    auto match_prefetch = [&]() __attribute__((always_inline)) {
-      const uint32_t ml = (uint32_t)(SP::match_lane >= 0 ? SP::match_lane : 0);
-      const uint32_t msk = rdlane(ht_mask, ml), base = rdlane(hto, ml);
-      const uint32_t lim = (rdlane(m_limit, ml) + 1u) & msk;                 // m_limit once this byte is stored
-      const uint32_t off = lim - rdlane(cm_pre, ml);                        // the candidate's distance, should the byte end unmatched
-      va_pre = __builtin_amdgcn_raw_buffer_load_b8(rsrc, base + ((lim - lane - 1u) & msk), 0, 0);
-      vb_pre = __builtin_amdgcn_raw_buffer_load_b8(rsrc, base + ((lim - lane - off - 1u) & msk), 0, 0);
-      mbn_pre = __builtin_amdgcn_raw_buffer_load_b8(rsrc, l_match ? base + ((lim - off) & msk) : kOob, 0, 0);
-      mbc_pre = __builtin_amdgcn_raw_buffer_load_b8(rsrc, l_match ? base + ((lim - m_ptr) & msk) : kOob, 0, 0);
-    };
-    // Predictor.update's MATCH part at the byte boundary (Predictor.cs:391-410); c is already in the history and the
-    // hash index, m_limit advanced
-    auto match_boundary = [&](uint32_t cb) __attribute__((always_inline)) {
-      const bool zero = m_len == 0;
-      const uint32_t nptr = m_limit - cm_pre;
-      const bool need = l_match && zero && (nptr & ht_mask) != 0;
-      m_ptr = (l_match && zero) ? nptr : m_ptr;
-      m_len = (l_match && !zero && m_len < 255) ? m_len + 1 : m_len;
-      if (__ballot(need) != 0) {                         // verify the candidate with the whole wave (Predictor.cs:403-405)
-        const uint32_t ml = (uint32_t)SP::match_lane;
-        const uint32_t lim = rdlane(m_limit, ml), off = rdlane(m_ptr, ml), msk = rdlane(ht_mask, ml);
-        const uint32_t a = lane == 0 ? cb : (va_pre & 255u);
-        const uint32_t b = ((lane + off) & msk) == 0 ? cb : (vb_pre & 255u);
-        uint64_t mism = __ballot(a != b);
-        uint32_t len = 64;
-        if (LIKELY(mism != 0)) len = (uint32_t)__builtin_ctzll(mism);
-        else {
-          const uint8_t *hp = slot_mem + rdlane(hto, ml);
-          for (uint32_t base = 64; base < 256; base += 64) {
-            const uint32_t t = base + lane;
-            const bool eq = t < 255 && hp[(lim - t - 1) & msk] == hp[(lim - t - off - 1) & msk];
-            mism = __ballot(!eq);
-            if (mism) { len += (uint32_t)__builtin_ctzll(mism); break; }
-            len += 64;
-          }
-        }
-        const uint32_t nl = len > 255 ? 255 : len;
-        m_len = l_match ? nl : m_len;
-        m_byte = l_match ? (((off - 1u) & msk) == 0 ? cb : (mbn_pre & 255u)) : m_byte;
-      } else {
-        const uint32_t cont = ((m_ptr - 1u) & ht_mask) == 0 ? cb : (mbc_pre & 255u);
-        m_byte = (l_match && m_len) ? cont : m_byte;
-      }
-      const uint32_t pw = *(lds_u32_p)(lds_off(S.pm01) + m_len * 4u);      // m_len stays 0 in the other lanes
-      pm0 = (int)(int16_t)(pw & 0xffffu); pm1 = (int)pw >> 16;
-    };
-
-    // Hash rows of a nibble (c8 == 1 or 16 <= c8 < 32), Predictor.find (Predictor.cs:550-567): see zh_chain2.hip
-    struct Probe { v4u r0, r1, r2; uint32_t h0, chk; };
-    auto rows_issue = [&](uint32_t c8, Probe &pr, bool on) __attribute__((always_inline)) {
-      const uint32_t cxt = hv + 16u * c8;
-      pr.chk = (cxt >> sizebits2) & 255;
-      pr.h0 = (cxt * 16u) & (ht_mask - 15u);
-      const uint32_t vo = (l_ii && on) ? hto + pr.h0 : kOob;
-      pr.r0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
-      pr.r1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo ^ 16u, 0, 0);
-      pr.r2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo ^ 32u, 0, 0);
-    };
-    // find on the three probes; rows this wave evicted after the probes' loads may have been issued (olda, old) are taken
-    // from the copies.  Result: the row and its place (nothing is written).
-    auto rows_pick = [&](const Probe &pr, const v4u &olda, uint32_t olda_off, bool olda_valid, const v4u &old, uint32_t old_off,
-                         bool old_valid, bool guard, v4u &row, uint32_t &sel) __attribute__((always_inline)) {
-      const uint32_t h0 = pr.h0, h1 = h0 ^ 16u, h2 = h0 ^ 32u;
-      v4u r0 = pr.r0, r1 = pr.r1, r2 = pr.r2;
-      const bool near = (olda_valid && ((olda_off ^ h0) & ~48u) == 0) || (old_valid && ((old_off ^ h0) & ~48u) == 0);
-      if (!guard || UNLIKELY(__ballot(near) != 0)) {
-        if (olda_valid && olda_off == h0) r0 = olda;
-        if (olda_valid && olda_off == h1) r1 = olda;
-        if (olda_valid && olda_off == h2) r2 = olda;
-        if (old_valid && old_off == h0) r0 = old;
-        if (old_valid && old_off == h1) r1 = old;
-        if (old_valid && old_off == h2) r2 = old;
-      }
-      const uint32_t chk = pr.chk;
-      const bool m0 = (r0.x & 255) == chk, m1 = (r1.x & 255) == chk, m2 = (r2.x & 255) == chk;
-      const uint32_t p0 = (r0.x >> 8) & 255, p1 = (r1.x >> 8) & 255, p2 = (r2.x >> 8) & 255;
-      const uint32_t victim = (p0 <= p1 && p0 <= p2) ? h0 : p1 < p2 ? h1 : h2;
-      sel = m0 ? h0 : m1 ? h1 : m2 ? h2 : victim;
-      const v4u fresh = {chk, 0, 0, 0};
-      row = m0 ? r0 : m1 ? r1 : m2 ? r2 : fresh;
-    };
-    auto row_take = [&](const v4u &row, uint32_t sel) __attribute__((always_inline)) {     // every lane holds the row of its component
-      rowoff = sel; rowvalid = true;
-      row_x = l_ii ? row.x : 0u; row_q1 = l_ii ? row.y : 0u; row_q2 = l_ii ? row.z : 0u; row_q3 = l_ii ? row.w : 0u;
-    };
-    // write the row of the finished nibble back (fire and forget) and hand its content to the caller
-    auto row_evict = [&](v4u &old, uint32_t &old_off, bool &old_valid) __attribute__((always_inline)) {
-      old = *(lds_u4_p)lds_off(&S.slot[ci]);
-      old_off = rowoff; old_valid = rowvalid && l_ii;
-      __builtin_amdgcn_raw_buffer_store_b128(old, rsrc, (old_valid && lane < NC) ? hto + rowoff : kOob, 0, 0);
-    };
-    auto mix_set = [&](uint32_t hq) __attribute__((always_inline)) {
-      mx_rb = vo_mix + (mx_base + __umul24(uni(hq) & mx_size1 & ~255u, mx_m4));
-    };
-    // rows of levels 2..4 of a nibble whose first row is c8n (1, or 16 + first nibble); level 1 comes staged / fetched ahead
-    auto mix_rows = [&](uint32_t c8n) __attribute__((always_inline)) {
+    NbV V;
+    {
+      uint32_t *w = reinterpret_cast<uint32_t *>(&V);
 #pragma unroll
-      for (int dd = 1; dd <= 4; ++dd) mrowl[dd] = mx_rb + __umul24((c8n << (dd - 1)) + pre[dd], mx_m4);
-#pragma unroll
-      for (int dd = 2; dd <= 4; ++dd) mwl[dd] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, mrowl[dd], 0, 0);
-    };
+      for (int i = 0; i < kNbVWords; ++i) w[i] = 0;
+      V.mx_rb = kOob;
+    }
 
     int failed = 0;
     for (uint32_t s = 0; s < n_seg; ++s) {
@@ -407,270 +883,61 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
       const uint64_t seg_off = uni64(L.segs[si].in_off);
       in_seek(in, seg_off, lane);
       if (s == 0) {                                      // first nibble of the block (h[] = 0)
-        Probe pr;
-        rows_issue(1u, pr, true);
+        NbProbe pr;
+        nb_rows_issue(K, V, 1u, pr, true);
         v4u row; uint32_t sel;
-        rows_pick(pr, v4u{0, 0, 0, 0}, 0u, false, v4u{0, 0, 0, 0}, 0u, false, false, row, sel);
-        if (lane < NC) *(lds_u4_p)lds_off(&S.slot[ci]) = row;
-        row_take(row, sel);
+        nb_rows_pick(pr, v4u{0, 0, 0, 0}, 0u, false, v4u{0, 0, 0, 0}, 0u, false, row, sel);
+        if (K.canon) *(lds_u4_p)lds_off(&S.slot[ci]) = row;
+        nb_row_take(K, V, row, sel);
         if (SP::nmix) {
-          mix_set(0u);
-          mix_rows(1u);
-          mwl[1] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, mrowl[1], 0, 0);
+          nb_mix_set(K, V, 0u);
+          nb_mix_rows(K, V, 1u);
+          V.mwl[1] = (int)__builtin_amdgcn_raw_buffer_load_b32(K.rsrc, V.mrowl[1], 0, 0);
         }
       }
 
-      v4u old1 = {0, 0, 0, 0}; uint32_t old1_off = 0; bool old1_valid = false;   // the first nibble's row as it was evicted
-      int w1_new = 0;                                  // mixer: row c8 = 1 of the byte's block after the first nibble
-      // ---- the eight bits of a byte (Decoder.cs:48-55 around Predictor.predict / update); j, bad, err as in zh_chain2.hip
-      auto decode_byte = [&](uint32_t &j, uint32_t &bad, uint32_t &err) __attribute__((always_inline)) -> uint32_t {
-          NB_STAMP(10);
-          int rnd12 = 1 << 12;                           // the weight updates' rounding addend, in a VGPR (zh_chain2.hip, C2V 64)
-          asm volatile("" : "+v"(rnd12));
-          // ---- the second nibble's hash rows, for the two values of the first nibble this group's prefix leaves open
-          // (16 candidates over the 8 groups), and the mixer weights of the rows they start with
-          Probe cand[2];
-          int cmw[2] = {0, 0};
-#pragma unroll
-          for (uint32_t k = 0; k < 2; ++k) {
-            rows_issue(16u + 2u * g + k, cand[k], act);
-            if (SP::nmix) cmw[k] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, act ? mx_rb + __umul24(16u + 2u * g + k, mx_m4) : kOob, 0, 0);
-          }
-          uint32_t cbyte = 0;
-          int p_l1 = 0, sqm_l1 = 0, mw_l1 = 0;            // mixer: level 1 of the first nibble (the same in every group)
-#pragma unroll
-          for (int nib = 0; nib < 2; ++nib) {
-            // ================= one nibble: four levels, every group on its own path =================
-            uint32_t st[5], ea[5], nsp[5], nA[5], nB[5], nsb[5];
-            v2u et[5];
-            int nmw[5] = {0, 0, 0, 0, 0};
-            st[1] = __builtin_amdgcn_ubfe(row_x, 8u, 8u);
-            st[2] = __builtin_amdgcn_ubfe(row_x, sh2, 8u);
-            st[3] = __builtin_amdgcn_ubfe(row_q1, sh3, 8u);
-            st[4] = __builtin_amdgcn_ubfe(b1 ? row_q3 : row_q2, sh4, 8u);
-#pragma unroll
-            for (int dd = 1; dd <= 4; ++dd) {
-              ea[dd] = tab + st[dd] * 8u;
-              et[dd] = *(lds_u2_p)ea[dd];
-              nsp[dd] = *(lds_u16_p)(ns_off + st[dd] * 4u);      // next(state, 0) | next(state, 1) << 8
-            }
-            // MATCH: the nibble the match predicts; a group whose path left it predicts 0 from there on
-            uint32_t ex = 0, mism = 0;
-            if (SP::match_lane >= 0) {
-              ex = (m_byte >> (nib ? 0u : 4u)) & 15u;
-              mism = (g ^ (ex >> 1)) & 7u;
-            }
-            uint32_t nv = 0;                               // the nibble's bits decoded so far (scalar)
-            int p = 0, sqp = 0, sqm = 0, pj = 0;
-            uint32_t eA = 0, eB = 0;
-#pragma unroll
-            for (int dd = 1; dd <= 4; ++dd) {
-              // ---- the entry of this level: from the table, or from a level of this path that trained the same entry
-              eA = et[dd].x; eB = et[dd].y;
-#pragma unroll
-              for (int k = 1; k < dd; ++k) {
-                const bool same = ea[dd] == ea[k];
-                eA = same ? nA[k] : eA;
-                eB = same ? nB[k] : eB;
-              }
-              // ---- predict (Predictor.cs:259-343)
-              int xs = pself;
-              if (SP::match_lane >= 0) {
-                const uint32_t cbit = (ex >> (4 - dd)) & 1u;
-                int pmv = cbit ? pm1 : pm0;
-                const uint32_t left = dd == 1 ? 0u : dd == 2 ? (mism & 4u) : dd == 3 ? (mism & 6u) : mism;
-                pmv = left ? 0 : pmv;
-                xs = l_match ? pmv : pself;
-              }
-              const int x = l_ii ? (int)eB : xs;
-              const int cw0 = (int)eA & isse_m;
-              const int cw1m = (int)((uint32_t)x << cshift);
-              p = x;
-#pragma unroll
-              for (uint32_t t = 0; t < SP::depth; ++t) p = med3i((__mul24(shr1(p), cw0) + cw1m) >> 16, -2048, 2047);
-              uint32_t psv;
-              if (SP::nmix) {
-                const int term = sum8(__mul24(mwl[dd] >> 8, p));     // lanes that do not feed the mixer hold weight 0
-                const int pmx = med3i(term >> 8, -2048, 2047);
-                if (ci == SP::mix_lane[0]) p = pmx;
-                sqm = (int)*(lds_u16_p)((uint32_t)(uintptr_t)lds_squash + (uint32_t)(pmx + 2048) * 2u);
-                psv = ((uint32_t)sqm << 17) | 0x10000u;
-              }
-              sqp = (int)*(lds_u16_p)((uint32_t)(uintptr_t)lds_squash + (uint32_t)(p + 2048) * 2u);
-              if (!SP::nmix) psv = ((uint32_t)sqp << 17) | 0x10000u;
-              if (SP::nmix && nib == 0 && dd == 1) { p_l1 = p; sqm_l1 = sqm; mw_l1 = mwl[1]; }
-              asm("" : "+v"(psv));
-              pj = shr1(p);                              // ISSE update: the prediction of the component before
-              // ---- decode (Decoder.cs:136-158): the split factor of the group the decoded bits lead to
-              const uint32_t lsel = (nv << (4 - dd)) * NC + SP::final_lane;
-              const uint32_t ps = rdlane(psv, lsel);
-              uint32_t jb = uni(j), xr;
-              d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr);   // (already scalar: says so to the compiler)
-              ZH_DEC_STEP_LITE(d, ps, jb, xr);
-              j = jb;
-              if (UNLIKELY(xr < 0x1000000u)) {
-                const uint32_t was = bad;
-                uint32_t later = 0;                       // after the byte's last bit the next EOS step re-checks by itself
-                if (dec_renorm_chk(d, in, lane, (nib == 1 && dd == 4) ? later : bad) && !err) err = was ? (uint32_t)-ZH_E_CORRUPT : (uint32_t)-ZH_E_EOF;
-              }
-              const uint32_t y = uni(j & 1u);
-              nv = nv * 2u + y;
-              // ---- update (Predictor.cs:363-461): levels 1-3 with the group's own bit, level 4 with the decoded one
-              const uint32_t yl = dd < 4 ? ybit[dd] : y;
-              const int ey = yl ? 32767 : 0;
-              const int e = ey - sqp;
-              nsb[dd] = __builtin_amdgcn_ubfe(nsp[dd], yl * 8u, 8u);
-              const uint32_t ncm = eA + (uint32_t)((int)(ey - (int)(eA >> 8)) >> 2);
-              const int npst = *(lds_i16_p)((uint32_t)(uintptr_t)lds_stretch + ((ncm >> 7) & 0x1fffeu));
-              const int nw0 = med3i((int)eA + ((__mul24(e, pj) + rnd12) >> 13), -(1 << 19), (1 << 19) - 1);
-              const int nw1 = med3i((int)eB + ((e + 16) >> 5), -(1 << 19), (1 << 19) - 1);
-              nA[dd] = l_isse ? (uint32_t)nw0 : ncm;
-              nB[dd] = l_isse ? (uint32_t)nw1 : (uint32_t)npst;
-              if (SP::nmix) {                            // MIX (Predictor.cs:427-439)
-                const int eq = __mul24(ey - sqm, mx_rate) >> 4;
-                nmw[dd] = med3i(mwl[dd] + ((__mul24(eq, p) + rnd12) >> 13), -(1 << 19), (1 << 19) - 1);
-              }
-              if (dd == 2 && nib == 0 && SP::match_lane >= 0) { /* nothing: MATCH's boundary requests go out at the nibble switch */ }
-            }
-            NB_STAMP(nib);
-            // ---- commit: the group the nibble's first three bits name
-            const uint32_t gw = nv >> 1;
-            if (act && g == gw) {
-#pragma unroll
-              for (int dd = 1; dd <= 4; ++dd) *(lds_u2_p)ea[dd] = v2u{nA[dd], nB[dd]};
-#pragma unroll
-              for (int dd = 1; dd <= 4; ++dd) *(lds_u8_p)(wrow + (node[dd] & wrow_mask)) = (uint8_t)nsb[dd];
-            }
-            if (SP::nmix) {
-#pragma unroll
-              for (int dd = 1; dd <= 4; ++dd) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)nmw[dd], rsrc, (act && g == gw) ? mrowl[dd] : kOob, 0, 0);
-            }
-            if (SP::nmix && nib == 0) {
-              // row c8 = 1 of this byte's block as it is now, in every group (level 1 is the same everywhere; y1 is known): should
-              // the next byte have the same mixer context, the helper's copy of that row may predate the store above
-              const int eq1 = __mul24(((nv & 8u) ? 32767 : 0) - sqm_l1, mx_rate) >> 4;
-              w1_new = med3i(mw_l1 + ((__mul24(eq1, p_l1) + rnd12) >> 13), -(1 << 19), (1 << 19) - 1);
-            }
-            if (SP::match_lane >= 0) {                    // MATCH (Predictor.cs:383-384): a miss ends the match
-              const bool miss = nv != ex;
-              m_len = miss ? 0u : m_len; pm0 = miss ? 0 : pm0; pm1 = miss ? 0 : pm1;
-            }
-            NB_STAMP(2 + nib);
-            if (nib == 0) {
-              // ---- second nibble (Predictor.cs:267-270: c8 & 0xf0 == 16): its rows were requested when the byte began
-              cbyte = nv;
-              v4u old; uint32_t old_off; bool old_valid;
-              row_evict(old, old_off, old_valid);
-              old1 = old; old1_off = old_off; old1_valid = old_valid;
-              if (SP::nmix > 0) c2_put0(&S.mb_nib, bseq << 8 | (nv & 15u));       // (see zh_chain2.hip for what the helper's loads must see)
-              const bool k1 = (nv & 1u) != 0;
-              Probe pr;
-              pr.h0 = k1 ? cand[1].h0 : cand[0].h0; pr.chk = k1 ? cand[1].chk : cand[0].chk;
-              pr.r0 = k1 ? cand[1].r0 : cand[0].r0; pr.r1 = k1 ? cand[1].r1 : cand[0].r1; pr.r2 = k1 ? cand[1].r2 : cand[0].r2;
-              v4u row; uint32_t sel;
-              rows_pick(pr, oldb, oldb_off, oldb_valid, old, old_off, old_valid, false, row, sel);   // (oldb: written back just before the candidates were requested)
-              if (act && g == gw) {
-                *(lds_u4_p)lds_off(&S.slot[ci]) = row;
-                S.slotoff[ci] = sel;
-                if (SP::nmix) S.mixb[ci] = (uint32_t)(k1 ? cmw[1] : cmw[0]);
-              }
-              asm volatile("" ::: "memory");
-              {
-                const v4u rowb = *(lds_u4_p)lds_off(&S.slot[ci]);
-                const uint32_t selb = S.slotoff[ci];
-                row_take(rowb, selb);
-                if (SP::nmix) { mwl[1] = l_feed ? (int)S.mixb[ci] : 0; mix_rows(16u + nv); }
-              }
-              if (SP::nmix == 0) c2_put0(&S.mb_nib, bseq << 8 | (nv & 15u));      // min: after the rows requested at the byte's start were consumed
-              if (SP::match_lane >= 0) match_prefetch();
-              NB_STAMP(4);
-            } else cbyte = cbyte * 16u + nv;
-          }
-          return cbyte;
-      };
-      // ---- byte boundary: MATCH (Predictor.cs:391-410), h[] and the rows of the next byte from the helper wave
-      auto boundary = [&](int c) __attribute__((always_inline)) -> bool {
-            v4u sg_row = {0, 0, 0, 0}; uint32_t sg_sel = 0; int sg_mw = 0;
-            if (SP::match_lane >= 0) {                   // still with the h[i] of the byte just coded (update0 runs before z.run)
-              __builtin_amdgcn_raw_buffer_store_b8((uint8_t)c, rsrc, (l_match && lane < NC) ? hto + (m_limit & ht_mask) : kOob, 0, 0);
-              m_limit = l_match ? (m_limit + 1) & ht_mask : m_limit;
-              __builtin_amdgcn_raw_buffer_store_b32(m_limit, rsrc, (l_match && lane < NC) ? cmo + (hv & cm_mask) * 4u : kOob, 0, 0);   // (its old value: cm_pre)
-            }
-            c2_put0(&S.mb_byte, bseq << 8 | (uint32_t)c);
-            NB_STAMP(5);
-            const uint32_t lo_ = (uint32_t)c & 15u, un_ = unit < (uint32_t)kSpecUnits ? unit : 0u;
-            auto read_staged = [&]() __attribute__((always_inline)) {
-              hv = S.hspec[ci & ((1u << SP::hh) - 1u)][lo_];
-              sg_row = *(lds_u4_p)lds_off(&S.selrow[un_][lo_]); sg_sel = S.seloff[un_][lo_];
-              if (SP::nmix) { const uint32_t jj = ci - SP::mix_j0[0]; sg_mw = (int)S.mixst[0][lo_][jj & 15u]; }
-            };
-            {
-              const uint32_t rdy_v = __hip_atomic_load(&S.mb_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              asm volatile("" ::: "memory");             // (the flag first: what is read behind it is what the flag vouches for)
-              read_staged();
-              if (UNLIKELY(uni(rdy_v) != bseq)) {        // not yet: wait, then read again
-                if (helper_ok) helper_ok = c2_wait(&S.mb_ready, bseq);
-                asm volatile("" ::: "memory");
-                read_staged();
-              }
-            }
-            if (!helper_ok) return false;                  // the helper wavefront stopped answering (cannot happen by design)
-            ++bseq;
-            NB_STAMP(6);
-            const uint32_t lo = (uint32_t)c & 15u;
-            v4u old; uint32_t old_off; bool old_valid;
-            row_evict(old, old_off, old_valid);
-            Probe pr;
-            {
-              const uint32_t cxt = hv + 16u;
-              pr.chk = (cxt >> sizebits2) & 255;
-              pr.h0 = (cxt * 16u) & (ht_mask - 15u);
-            }
-            if (SP::nmix) {
-              const uint32_t rb_was = mx_rb;
-              mix_set(rdlane(hv, SP::mix_lane[0]));
-              mwl[1] = l_feed ? (mx_rb == rb_was ? w1_new : sg_mw) : 0;
-              mix_rows(1u);
-            }
-            if (SP::match_lane >= 0) {
-              match_boundary((uint32_t)c);
-              cm_pre = __builtin_amdgcn_raw_buffer_load_b32(rsrc, l_match ? cmo + (hv & cm_mask) * 4u : kOob, 0, 0);
-            }
-            const bool near = (old1_valid && ((old1_off ^ pr.h0) & ~48u) == 0) || (old_valid && ((old_off ^ pr.h0) & ~48u) == 0);
-            v4u row = sg_row; uint32_t sel = sg_sel;
-            if (UNLIKELY(__ballot(near) != 0)) {         // something this wave wrote late lies in a probed bucket: the probes, patched
-              pr.r0 = *(lds_u4_p)lds_off(&S.rowst[un_][0][lo]);
-              pr.r1 = *(lds_u4_p)lds_off(&S.rowst[un_][1][lo]);
-              pr.r2 = *(lds_u4_p)lds_off(&S.rowst[un_][2][lo]);
-              rows_pick(pr, old1, old1_off, old1_valid, old, old_off, old_valid, false, row, sel);
-            }
-            if (lane < NC) *(lds_u4_p)lds_off(&S.slot[ci]) = row;
-            row_take(row, sel);
-            oldb = old; oldb_off = old_off; oldb_valid = old_valid;
-            asm volatile("" ::: "memory");
-            NB_STAMP(7);
-            return true;
-      };
       for (;;) {                                       // one decoded byte per iteration
         uint32_t bad = 0, rn = 0, j = 0, err = 0;
         bool after_eos = false;
-        // ---- the common case as a loop of its own: post-processor in PASS state, nothing unusual in the byte.  Whatever else
-        // happens (priming, end of segment, a renormalisation or a range error at the EOS flag) leaves it for the general form below
-        if (LIKELY(pp_state == 1)) {
-          for (;;) {
-            d.low = uni(d.low); d.high = uni(d.high); d.curr = uni(d.curr);
-            if (UNLIKELY(d.curr == 0)) break;
-            bad = 0; j = 0;
-            ZH_DEC_STEP(d, 0u, j, bad, rn);            // EOS flag: p = 0
-            if (UNLIKELY((bad | rn | j) != 0)) { after_eos = true; break; }
-            err = 0;
-            const uint32_t cb = decode_byte(j, bad, err);
-            if (UNLIKELY((err | bad) != 0)) { status = err ? -(int)err : ZH_E_CORRUPT; break; }
-            if (UNLIKELY(!boundary((int)cb))) { status = -24; break; }     // ZPAQHIP_E_HIP
-            out_put(ob, cb, lane);
-            NB_STAMP(9);
+        // ---- the common case runs in nb_fast
+        if (LIKELY(pp_state == 1 && helper_ok)) {
+          if (in.k + 40u > in.avail && in.cbase + in.avail < in.total) in_seek(in, in_pos(in), lane);   // nb_fast wants >= 40 coded bytes in the chunk: re-base it at the cursor
+          if (d.curr != 0 && in.avail >= 40u && in.k + 40u <= in.avail && ob.room != 0) {
+            {
+              const uint32_t *w = reinterpret_cast<const uint32_t *>(&V);
+#pragma unroll
+              for (int i = 0; i < kNbVWords; ++i) S.fxv[i][lane] = w[i];
+              S.fxv[kNbVWords][lane] = in.cur;
+              S.fxv[kNbVWords + 1][lane] = ob.park;
+            }
+            if (lane == 0) {
+              S.fxs[kFxLow] = d.low; S.fxs[kFxHigh] = d.high; S.fxs[kFxCurr] = d.curr; S.fxs[kFxK] = in.k; S.fxs[kFxAvail] = in.avail;
+              S.fxs[kFxBseq] = bseq; S.fxs[kFxModel] = model_i; S.fxs[kFxWord] = ob.word; S.fxs[kFxRoom] = ob.room;
+              S.fxs[kFxLenLo] = (uint32_t)ob.len; S.fxs[kFxLenHi] = (uint32_t)(ob.len >> 32);
+              S.fxs[kFxStoredLo] = (uint32_t)ob.stored; S.fxs[kFxStoredHi] = (uint32_t)(ob.stored >> 32);
+              S.fxs[kFxCapLo] = (uint32_t)ob.cap; S.fxs[kFxCapHi] = (uint32_t)(ob.cap >> 32);
+              S.fxs[kFxBaseLo] = (uint32_t)(uintptr_t)ob.base; S.fxs[kFxBaseHi] = (uint32_t)((uintptr_t)ob.base >> 32);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            nb_fast<SP, PROF, LDS>(&L, &S);
+            asm volatile("" ::: "memory");
+            {
+              uint32_t *w = reinterpret_cast<uint32_t *>(&V);
+#pragma unroll
+              for (int i = 0; i < kNbVWords; ++i) w[i] = S.fxv[i][lane];
+              ob.park = S.fxv[kNbVWords + 1][lane];
+            }
+            d.low = uni(S.fxs[kFxLow]); d.high = uni(S.fxs[kFxHigh]); d.curr = uni(S.fxs[kFxCurr]); in.k = uni(S.fxs[kFxK]);
+            bseq = uni(S.fxs[kFxBseq]);
+            ob.word = uni(S.fxs[kFxWord]); ob.room = uni(S.fxs[kFxRoom]);
+            ob.len = (uint64_t)uni(S.fxs[kFxLenLo]) | (uint64_t)uni(S.fxs[kFxLenHi]) << 32;
+            ob.stored = (uint64_t)uni(S.fxs[kFxStoredLo]) | (uint64_t)uni(S.fxs[kFxStoredHi]) << 32;
+            const uint32_t why = uni(S.fxs[kFxWhy]);
+            if (PROF) for (int i = 0; i < 16; ++i) P.prof[i] += (uint64_t)S.fxs[kFxProf + 2 * i] | (uint64_t)S.fxs[kFxProf + 2 * i + 1] << 32;
+            if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(P.tprev)::"memory"); }
+            if (why == 2) { status = (int)uni(S.fxs[kFxStatus]); if (status == -24) helper_ok = false; break; }
+            if (why == 1) { after_eos = true; j = uni(S.fxs[kFxJ]); bad = uni(S.fxs[kFxBad]); rn = uni(S.fxs[kFxRn]); }
           }
-          if (status) break;
         }
         // ---- Decoder.decompress prologue (Decoder.cs:36-45)
         if (!after_eos) {
@@ -692,9 +959,9 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
           c = -1;
         } else {
           err = 0;
-          c = (int)decode_byte(j, bad, err);
+          c = (int)nb_decode_byte<SP, PROF, false>(K, V, S, d, in, j, bad, err, bseq, P);
           if (UNLIKELY(err | bad)) { status = err ? -(int)err : ZH_E_CORRUPT; break; }
-          if (UNLIKELY(!boundary(c))) { status = -24; break; }             // ZPAQHIP_E_HIP
+          if (UNLIKELY((!nb_boundary<SP, PROF>(K, V, S, c, bseq, helper_ok, P)))) { status = -24; break; }             // ZPAQHIP_E_HIP
         }
 
         // ---- PostProcessor.write(c) (PostProcessor.cs:37-86)
@@ -731,7 +998,7 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
             pp_state = 5;
           }
         }
-        NB_STAMP(9);
+        { NbProf &P_ = P; (void)P_; }
         if (c < 0) break;
       }
 
@@ -748,7 +1015,7 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
       }
     }
     if (PROF && lane == 0 && L.debug)
-      for (int i = 0; i < 16; ++i) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)prof[i]);
+      for (int i = 0; i < 16; ++i) atomicAdd((unsigned long long *)&L.debug[i], (unsigned long long)P.prof[i]);
     {                                                   // the helper wave leaves the block; its late commit of the last byte
       ++cmd_seq;                                        // (S.mreg / S.hreg) must be in LDS before this wave zeroes them again
       c2_put0(&S.mb_cmd, cmd_seq << 2 | kC2End);
