@@ -120,7 +120,9 @@ typedef struct zpaqhip_opts {
                                  4 lane-per-component without model specialisation; 5 the run-time-level form of the
                                  lane-per-component kernel also for the built-in min/mid/max models (cross-check);
                                  7 / 8: ignored (= auto) by the product build; a library built with `make EXPERIMENTS=1` runs the
-                                 measured-and-not-kept three-wave form of mid/max there (tools/experiments/zh_chain3.hip) */
+                                 measured-and-not-kept three-wave form of mid/max there (tools/experiments/zh_chain3.hip);
+                                 9: the built-in min / mid models on the bit-at-a-time kernels of rounds 2-4 (zh_chain2.hip) instead of
+                                 the nibble-at-a-time ones (zh_nibble.hip): cross-check and A/B runs */
   uint64_t zpaql_budget;      /* runaway-program guard, per run() call: max ZPAQL instructions on the interpreter, max backward
                                  jumps in an ahead-of-time translated program (a translation checks where it can loop);
                                  0 = default (1<<32).  Exceeding it ends the block with ZPAQHIP_E_BUDGET */

@@ -80,6 +80,18 @@ S.M0, S.M1, S.M2 = "s[86:87]", "s[88:89]", "s[90:91]"      # FIND (the decoder t
 S.win = "s[100:101]"
 
 L = []          # output lines
+PROF = False    # the *_PROF variant: s_memtime stamps, cycles per stage summed in v100.. (lane-uniform), written out at exit
+
+
+def stamp(i):
+    if PROF:
+        o(f"""
+      s_waitcnt lgkmcnt(0)
+      s_memtime s[62:63]
+      s_waitcnt lgkmcnt(0)
+      s_sub_u32 s61, s62, s60
+      s_mov_b32 s60, s62
+      v_add_u32_e32 v{100 + i}, s61, v{100 + i}""")
 
 
 def o(s=""):
@@ -261,6 +273,7 @@ def nibble(n):
       s_and_b64 {S.win}, vcc, {S.mact}
       s_waitcnt lgkmcnt(0)
       v_cndmask_b32_e64 {R.nB[4]}, {T[6]}, {T[1]}, {S.misse}""")
+    stamp(1 if n == 0 else 4)
     # ---- commit: the group the first three bits name writes its four entries (in path order) and its four bit histories
     o(f"s_and_saveexec_b64 {S.sav}, {S.win}")
     for d in range(1, 5):
@@ -368,7 +381,15 @@ def gen():
       s_mov_b32 {S.bad}, 0
       s_mov_b32 {S.fail}, 0
       s_mov_b32 %[why], 0
-      s_mov_b32 %[m0s], m0
+      s_mov_b32 %[m0s], m0""")
+    if PROF:
+        for i in range(12):
+            o(f"v_mov_b32_e32 v{100 + i}, 0")
+        o("""
+      s_memtime s[62:63]
+      s_waitcnt lgkmcnt(0)
+      s_mov_b32 s60, s62""")
+    o(f"""
       s_waitcnt lgkmcnt(0)
       s_branch .Lbyte_%=
       .p2align 6""")
@@ -412,8 +433,10 @@ def gen():
       buffer_load_dwordx4 {R.c4[k][0]}, {T[1]}, %[rs], 0 offen
       buffer_load_dwordx4 {R.c4[k][1]}, {T[2]}, %[rs], 0 offen
       buffer_load_dwordx4 {R.c4[k][2]}, {T[3]}, %[rs], 0 offen""")
+    stamp(0)
     # ======== first nibble
     nibble(0)
+    stamp(2)
     # ======== nibble switch (Predictor.cs:267-270: c8 & 0xf0 == 16): the row of the finished nibble, the candidate the
     # decoded value names, find, the row to every group through LDS, then the write-back (behind the loads it might wait for)
     o(f"""
@@ -450,8 +473,10 @@ def gen():
       ds_write_b32 {R.k_mb}, {T[0]}
       s_mov_b64 exec, -1
       s_waitcnt lgkmcnt(1)""")
+    stamp(3)
     # ======== second nibble
     nibble(1)
+    stamp(5)
     # ======== byte boundary: the byte to the helper wave, its staging for this value (h[], the row Predictor.find settles on)
     o(f"""
       s_lshl_b32 {S.c}, {S.v1}, 4
@@ -481,6 +506,7 @@ def gen():
       s_cmp_lg_u32 {S.t0}, %[bseq]
       s_cbranch_scc1 .Lspin_%=
       s_waitcnt lgkmcnt(0)""")
+    stamp(6)
     # write-back of the second nibble's row; is one of the two rows written late in the bucket the helper probed?
     o(f"""
       v_add_u32_e32 {T[0]}, {R.k_evo}, {R.oboff}
@@ -507,6 +533,7 @@ def gen():
       v_mov_b32_e32 {R.rq3}, v201
       v_mov_b32_e32 {R.rowoff}, {sel}
       s_add_u32 %[bseq], %[bseq], 1""")
+    stamp(7)
     # ======== PostProcessor.write in PASS state (ZPAQL.outc, ZPAQL.cs:201-207): the dword assembled on the scalar unit
     o(f"""
       s_add_u32 {S.t0}, %[vlo], %[nput]
@@ -519,15 +546,18 @@ def gen():
       s_cselect_b32 %[word], 0, %[word]
       s_or_b32 %[word], %[word], {S.t3}
       s_cmp_lg_u32 {S.t1}, 3
-      s_cbranch_scc1 .Lbyte_%=
+      s_cbranch_scc1 .Lnext_%=
       s_bfe_u32 {S.t1}, {S.t0}, 0x60002
       s_mov_b32 m0, {S.t1}
       s_and_b32 {S.t2}, {S.t0}, 0xff
       v_writelane_b32 {R.park}, %[word], m0
       s_cmp_lg_u32 {S.t2}, 0xff
-      s_cbranch_scc1 .Lbyte_%=
+      s_cbranch_scc1 .Lnext_%=
       s_mov_b32 %[why], 3
       s_branch .Lexit_%=""")
+    label("next")
+    stamp(8)
+    o("s_branch .Lbyte_%=")
     # ======== out of line
     renorm_block("00")
     for n in range(2):
@@ -575,6 +605,9 @@ def gen():
     vregs = [R.rx, R.rq1, R.rq2, R.rq3, R.rowoff, R.hv, R.ob[0], R.ob[1], R.ob[2], R.ob[3], R.oboff, R.park]
     for i, r in enumerate(vregs):
         o(f"ds_write_b32 %[vb], {r} offset:{i * 256}")
+    if PROF:
+        for i in range(12):
+            o(f"ds_write_b32 %[vb], v{100 + i} offset:{(len(VNAMES) + i) * 256}")
     o(f"""
       s_mov_b32 m0, %[m0s]
       s_mov_b32 %[obad], {S.bad}
@@ -582,9 +615,47 @@ def gen():
       s_waitcnt lgkmcnt(0)""")
 
 
-def main():
+def emit(name, prof):
+    global PROF
+    PROF = prof
+    del L[:]
     gen()
-    clob = ["memory", "scc", "vcc"] + [f"s{i}" for i in range(64, 102)] + [f"v{i}" for i in range(128, 256)]
+    clob = ["memory", "scc", "vcc"] + [f"s{i}" for i in range(60 if prof else 64, 102)] + [f"v{i}" for i in range(100 if prof else 128, 256)]
+    text = f"""#define {name}(low_, high_, curr_, k_, bseq_, nput_, room_, word_, why_, obad_, ofail_, m0s_, klim_, vlo_, kb_, vb_, rs_, sqb_, nsb_) \\
+  asm volatile( \\
+"""
+    for ln in L:
+        text += '  "' + ln.replace('"', '\\"') + '\\n\\t" \\\n'
+    text += """  : [low] "+s"(low_), [high] "+s"(high_), [curr] "+s"(curr_), [k] "+s"(k_), [bseq] "+s"(bseq_), [nput] "+s"(nput_), [room] "+s"(room_), \\
+    [word] "+s"(word_), [why] "=&s"(why_), [obad] "=&s"(obad_), [ofail] "=&s"(ofail_), [m0s] "=&s"(m0s_) \\
+  : [klim] "s"(klim_), [vlo] "s"(vlo_), [kb] "v"(kb_), [vb] "v"(vb_), [rs] "s"(rs_), [sqb] "s"(sqb_), [nsb] "s"(nsb_) \\
+  : """ + ", ".join('"' + c + '"' for c in clob) + ")\n"
+    return text, len(L)
+
+
+def main():
+    t0, n0 = emit("ZH_NB_FAST_MIN_LOOP", False)
+    t1, _ = emit("ZH_NB_FAST_MIN_LOOP_PROF", True)
+    head = f"""// zh_nb_fast.h — GENERATED by tools/gen_nb_asm.py (do not edit: edit the generator and run it).
+// The steady-state byte loop of nb_fast (zh_nibble.hip) for the built-in min model, hand-laid gfx950 assembly.
+// ZH_NB_FAST_MIN_LOOP_PROF is the same loop with s_memtime stamps (cycles per stage, kNbS_count + i of the state area).
+#pragma once
+#define ZH_NB_FAST_MIN 1
+enum : int {{ {", ".join("kNbK_" + n + (" = 0" if i == 0 else "") for i, n in enumerate(KNAMES))}, kNbK_count }};
+enum : int {{ {", ".join("kNbS_" + n + (" = 0" if i == 0 else "") for i, n in enumerate(VNAMES))}, kNbS_count }};
+// clang-format off
+"""
+    text = head + t0 + t1 + "// clang-format on\n"
+    if len(sys.argv) > 1 and sys.argv[1] == "--check":
+        cur = open(OUT).read() if os.path.exists(OUT) else ""
+        sys.exit(0 if cur == text else 1)
+    with open(OUT, "w") as f:
+        f.write(text)
+    print(f"{OUT}: {n0} lines of assembly")
+
+
+def _old_main():
+    clob = []
     head = f"""// zh_nb_fast.h — GENERATED by tools/gen_nb_asm.py (do not edit: edit the generator and run it).
 // The steady-state byte loop of nb_fast (zh_nibble.hip) for the built-in min model, hand-laid gfx950 assembly.
 #pragma once

@@ -451,7 +451,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     else if (g > ZH_FAM_CHAIN && zh_chain3_has(g - ZH_FAM_CHAIN) && (opts.kernel == 7 || opts.kernel == 8))   // decoder ‖ model ‖ helper wave: experiment build only
       HIPCHK(zh_launch_chain3(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof ? 2 : opts.kernel == 7));
 #endif
-    else if (g > ZH_FAM_CHAIN && zh_nibble_has(g - ZH_FAM_CHAIN) && opts.kernel == 9)   // nibble-at-a-time form (zh_nibble.hip)
+    else if (g > ZH_FAM_CHAIN && zh_nibble_has(g - ZH_FAM_CHAIN) && opts.kernel != 9 && opts.kernel != 5)   // min / mid a nibble at a time (zh_nibble.hip); 9: the bit-at-a-time form below
       HIPCHK(zh_launch_nibble(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));
     else if (g > ZH_FAM_CHAIN && zh_chain2_has(g - ZH_FAM_CHAIN) && opts.kernel != 5)   // per-model bit loop (zh_chain2.hip)
       HIPCHK(zh_launch_chain2(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof));

@@ -68,7 +68,7 @@ struct alignas(16) NbLds {
   uint32_t fxs[96];                           // nb_fast: scalars in and out (kFx*)
   uint32_t fxv[64][64];                       // ... and per-lane words (NbV, the coded chunk, the parked output)
   uint32_t fxk[kNbK_count][64];               // zh_nb_fast.h: per-lane constants of the assembly loop
-  uint32_t fxa[kNbS_count][64];               // ... and the per-lane state it loads and stores
+  uint32_t fxa[kNbS_count + 12][64];          // ... and the per-lane state it loads and stores (+ the stamped variant's 12 sums)
   uint32_t hreg[kHWords];
   uint8_t mreg[kMBytes];
   uint32_t r[256], pr[256];
@@ -628,7 +628,7 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
   const uint32_t klim = in.avail >= 40u ? in.avail - 40u : 0u;
   uint32_t vlo = (uint32_t)(uintptr_t)ob.base + (uint32_t)ob.len;     // low bits of the virtual output position
   uint32_t nput = 0, room = ob.room, word = ob.word;
-  if constexpr (SP::id == 1 && !PROF && ZH_NB_ASM != 0) {
+  if constexpr (SP::id == 1 && ZH_NB_ASM != 0) {
     // ---- the loop in assembly (zh_nb_fast.h, tools/gen_nb_asm.py): constants and state through LDS
     if (lds_off(S.stretch) == 0 && V.rowvalid) {
       const uint32_t hmask_ = (1u << SP::hh) - 1u;
@@ -661,7 +661,12 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
         S.fxa[kNbS_park][lane] = ob.park;
         const uint32_t vlo_s = uni(vlo);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ZH_NB_FAST_MIN_LOOP(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb);
+        if constexpr (PROF) {
+          ZH_NB_FAST_MIN_LOOP_PROF(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb);
+          for (int i = 0; i < 12; ++i) P.prof[i] += S.fxa[kNbS_count + i][0];
+        } else {
+          ZH_NB_FAST_MIN_LOOP(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb);
+        }
         ob.park = S.fxa[kNbS_park][lane];
         if (asm_why != 3) break;
         ob.len += nput; ob.word = word; ob.room = room; vlo += nput; nput = 0;      // the parked 256-byte chunk is complete
