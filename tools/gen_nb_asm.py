@@ -216,10 +216,23 @@ def nibble(n):
       s_waitcnt lgkmcnt(1)
       v_bfe_u32 {R.nsb[d]}, {R.nsp[d]}, {getattr(R, 'k_ys%d' % d)}, 8""")
         else:
+            # level 4: the bit is not the group's own.  The ICM half for BOTH values, so that its stretch look-ups travel under
+            # the decode instead of behind it
             o(f"""
-      s_nop 0
+      v_sub_u32_e32 {T[5]}, 0, {T[7]}
+      v_sub_u32_e32 {T[6]}, 0x7fff, {T[7]}
+      v_ashrrev_i32_e32 {T[5]}, 2, {T[5]}
+      v_ashrrev_i32_e32 {T[6]}, 2, {T[6]}
+      v_add_u32_e32 {T[5]}, {T[5]}, {eA}
+      v_add_u32_e32 {T[6]}, {T[6]}, {eA}
+      v_lshrrev_b32_e32 {R.u[0]}, 7, {T[5]}
+      v_lshrrev_b32_e32 {R.u[1]}, 7, {T[6]}
+      v_and_b32_e32 {R.u[0]}, 0x1fffe, {R.u[0]}
+      v_and_b32_e32 {R.u[1]}, 0x1fffe, {R.u[1]}
+      ds_read_i16 {T[2]}, {R.u[0]}
+      ds_read_i16 {T[3]}, {R.u[1]}
       v_mov_b32_dpp {R.pj}, {R.p} row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1
-      s_waitcnt lgkmcnt(0)""")
+      s_waitcnt lgkmcnt(2)""")
         o(f"""
       v_lshl_or_b32 {R.psv}, {R.sq}, 17, {R.k_c10000}
       v_sub_u32_e32 {R.e}, {getattr(R, 'k_ey%d' % d) if d < 4 else R.sq}, {R.sq}""" if d < 4 else f"""
@@ -243,6 +256,18 @@ def nibble(n):
       s_or_b32 {S.lsel}, {S.lsel}, 1
       s_waitcnt lgkmcnt(0)
       v_cndmask_b32_e64 {R.nB[d]}, {T[6]}, {T[1]}, {S.misse}""")
+            if n == 0 and d == 3:
+                # three bits of the byte are known: the helper wave starts on the next byte's 32 candidates.  vmcnt(6): at most the
+                # six candidate-row loads of this byte are still out, so every store issued before them (the row written back at
+                # the last byte boundary) has been acknowledged — vector memory completes in issue order
+                o(f"""
+      s_waitcnt vmcnt(6)
+      s_lshl_b32 {S.t0}, %[bseq], 8
+      s_or_b32 {S.t0}, {S.t0}, {S.nv}
+      v_mov_b32_e32 {R.u[0]}, {S.t0}
+      s_mov_b64 exec, 1
+      ds_write_b32 {R.k_mb}, {R.u[0]}
+      s_mov_b64 exec, -1""")
         else:
             # ---- level 4: decode first, then the whole update with the decoded bit
             dec_step(tag, "")
@@ -250,13 +275,9 @@ def nibble(n):
       s_and_b32 {S.t0}, {S.nv}, 1
       s_cmp_lg_u32 {S.t0}, 0
       s_cselect_b32 {S.ey4}, 0x7fff, 0
+      s_cselect_b64 {S.mk}, -1, 0
       s_lshl_b32 {S.ys4}, {S.t0}, 3
-      v_sub_u32_e32 {T[7]}, {S.ey4}, {T[7]}
-      v_ashrrev_i32_e32 {T[7]}, 2, {T[7]}
-      v_add_u32_e32 {T[7]}, {T[7]}, {eA}
-      v_lshrrev_b32_e32 {T[5]}, 7, {T[7]}
-      v_and_b32_e32 {T[5]}, 0x1fffe, {T[5]}
-      ds_read_i16 {T[6]}, {T[5]}
+      v_cndmask_b32_e64 {T[7]}, {T[5]}, {T[6]}, {S.mk}
       v_sub_u32_e32 {R.e}, {S.ey4}, {R.sq}
       v_bfe_u32 {R.nsb[4]}, {R.nsp[4]}, {S.ys4}, 8
       v_mad_i32_i24 {T[0]}, {R.e}, {R.pj}, {R.k_rnd}
@@ -272,6 +293,7 @@ def nibble(n):
       v_cmp_eq_u32_e32 vcc, {S.t1}, {R.k_g}
       s_and_b64 {S.win}, vcc, {S.mact}
       s_waitcnt lgkmcnt(0)
+      v_cndmask_b32_e64 {T[6]}, {T[2]}, {T[3]}, {S.mk}
       v_cndmask_b32_e64 {R.nB[4]}, {T[6]}, {T[1]}, {S.misse}""")
     stamp(1 if n == 0 else 4)
     # ---- commit: the group the first three bits name writes its four entries (in path order) and its four bit histories
@@ -466,13 +488,7 @@ def gen():
       s_mov_b64 exec, {S.sav}
       ds_read_b128 {R.row4}, {R.k_slot}
       ds_read_b32 {R.rowoff}, {R.k_slotoff}
-      s_lshl_b32 {S.t0}, %[bseq], 8
-      s_or_b32 {S.t0}, {S.t0}, {S.nv}
-      v_mov_b32_e32 {T[0]}, {S.t0}
-      s_mov_b64 exec, 1
-      ds_write_b32 {R.k_mb}, {T[0]}
-      s_mov_b64 exec, -1
-      s_waitcnt lgkmcnt(1)""")
+      s_waitcnt lgkmcnt(0)""")
     stamp(3)
     # ======== second nibble
     nibble(1)
@@ -489,7 +505,7 @@ def gen():
       s_mov_b64 exec, -1
       ds_read_b128 {R.ob4}, {R.k_slot}
       v_mov_b32_e32 {R.oboff}, {R.rowoff}
-      s_and_b32 {S.t1}, {S.nv}, 15
+      s_and_b32 {S.t1}, {S.c}, 31
       s_lshl_b32 {S.t2}, {S.t1}, 4
       s_lshl_b32 {S.t1}, {S.t1}, 2
       v_add_u32_e32 {T[1]}, {S.t2}, {R.k_selrow}
@@ -591,8 +607,8 @@ def gen():
       v_mov_b32_e32 {R.u[1]}, {T[6]}
       v_add_u32_e32 {T[1]}, {S.t2}, {R.k_rowst}
       ds_read_b128 {R.c4[0][0]}, {T[1]}
-      ds_read_b128 {R.c4[0][1]}, {T[1]} offset:256
-      ds_read_b128 {R.c4[0][2]}, {T[1]} offset:512
+      ds_read_b128 {R.c4[0][1]}, {T[1]} offset:512
+      ds_read_b128 {R.c4[0][2]}, {T[1]} offset:1024
       s_waitcnt lgkmcnt(0)""")
     cold2 = find(R.c[0], R.u[0], R.u[1], [(R.o1off, R.o1), (R.oboff, R.ob)], row, sel, "b")
     o("s_branch .Ltaken_%=")

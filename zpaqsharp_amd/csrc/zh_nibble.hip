@@ -43,6 +43,11 @@ using namespace zhdev;
 
 namespace {
 
+// The helper wave starts when THREE bits of a byte are known and prepares the next byte for the 32 values it can still take
+// (zh_chain2.hip: four bits, 16 values).  The nibble-at-a-time decoder gets through a nibble in about the time a hash row takes
+// to arrive from HBM: with the later start it waited ~670 cycles per byte for the helper (profiles/r05/nb_stage_notes.txt).
+constexpr uint32_t kNbCand = 32;
+
 template <uint32_t NU>
 struct alignas(16) NbLds {
   static constexpr bool kMixLds = false;
@@ -58,11 +63,11 @@ struct alignas(16) NbLds {
   uint32_t slotoff[8];                        // place of slot[c] in the component's hash table
   uint32_t mixb[8];                           // the mixer weights of the second nibble's first row, from the group that fetched them
   // helper wave: what it prepares for the NEXT byte, for each of the 16 values the current byte can still take
-  uint32_t hspec[kSpecH][16];
-  v4u_ rowst[kSpecUnits][3][16];
-  uint32_t mixst[2][16][16];
-  v4u_ selrow[kSpecUnits][16];
-  uint32_t seloff[kSpecUnits][16];
+  uint32_t hspec[kSpecH][kNbCand];
+  v4u_ rowst[NU][3][kNbCand];
+  uint32_t mixst[kNbCand][8];
+  v4u_ selrow[NU][kNbCand];
+  uint32_t seloff[NU][kNbCand];
   uint32_t mb_nib, mb_byte, mb_ready;
   uint32_t mb_cmd, mb_ack, mb_model;
   uint32_t fxs[96];                           // nb_fast: scalars in and out (kFx*)
@@ -103,6 +108,157 @@ __device__ __forceinline__ int sum8(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
   v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
   return v;
+}
+
+// ---- the helper wave of the nibble kernels: c2_helper (zh_c2_common.h) for 32 candidates.  While the decoder wave finishes a
+// byte whose first three bits it has published, this wave runs HCOMP (the translated program, one candidate byte per lane)
+// for the 32 values the byte can still take and brings what the next byte starts with into LDS for each of them: h[], the
+// row Predictor.find settles on among its three probes (and the probes themselves, for the decoder's patch path), the
+// mixer row for c8 = 1.  When the decoder knows the byte it takes column `byte & 31`; this wave commits that candidate's
+// machine state.  It never decides anything: a late helper only makes the decoder wait.
+template <class SP, class LDS, bool PROF>
+__device__ void nb_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_block_slot) {
+  uint64_t hb_busy = 0, hb_slack = 0, hb_t0 = 0, hb_t1 = 0;   // PROF: start seen -> staging complete; staging complete -> byte seen
+  constexpr uint32_t NU = c2_units<SP>(), NH = 1u << SP::hh, RN = (NU + 1u) / 2u;
+  static_assert(NH <= (uint32_t)kSpecH && NU <= 8u, "staging size");
+  uint8_t *slot_mem = L.arena + (uint64_t)wg_block_slot * L.arena_stride;
+  const uint32_t cand = lane & (kNbCand - 1u), grp = lane >> 5;
+  uint32_t seen_cmd = 0;
+  for (;;) {
+    uint32_t cmd, sp = 0;
+    while ((cmd = c2_ld(&S.mb_cmd)) == seen_cmd) { __builtin_amdgcn_s_sleep(4); if (++sp > kC2Spin) return; }
+    seen_cmd = cmd;
+    if ((cmd & 3u) == kC2Exit) return;
+    if ((cmd & 3u) != kC2New) {
+      if (PROF && lane == 0 && L.debug) {
+        atomicAdd((unsigned long long *)&L.debug[14], (unsigned long long)hb_busy);
+        atomicAdd((unsigned long long *)&L.debug[15], (unsigned long long)hb_slack);
+      }
+      hb_busy = 0; hb_slack = 0;
+      c2_put0(&S.mb_ack, cmd); continue;
+    }   // End: acknowledged once this wave has left the block (its last commit is in LDS)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const ZhModel *M = &L.models[uni(c2_ld(&S.mb_model))];
+    const uint32_t arena_bytes = uni((uint32_t)M->arena_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slot_mem, 0, (int)arena_bytes, 0x00020000);
+    // this lane's units: u = grp, grp + 2, ... (rows of unit u for candidate `cand`)
+    uint32_t u_hto[RN], u_mask[RN], u_comp[RN], u_sb2[RN];
+    bool u_on[RN];
+#pragma unroll
+    for (uint32_t r = 0; r < RN; ++r) {
+      const uint32_t u = grp + 2u * r;
+      u_on[r] = u < NU;
+      uint32_t ci = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < NU; ++k) if (k == u) ci = c2_unit_comp<SP>(k);
+      const ZhComp *cp = &M->comp[ci];
+      u_comp[r] = ci; u_hto[r] = (uint32_t)cp->ht_off; u_mask[r] = cp->ht_mask; u_sb2[r] = (uint32_t)cp->arg[0] + 2u;
+    }
+    uint32_t mx_base = 0, mx_size1 = 0, mx_c1 = 0;
+    if (SP::nmix) {
+      const ZhComp &mc = M->comp[SP::mix_lane[0]];
+      mx_base = uni((uint32_t)mc.cm_off); mx_size1 = uni(mc.cm_mask); mx_c1 = 1u & (uint32_t)mc.arg[4];
+    }
+    uint32_t hb = 0, hc = 0, hd = 0, hf = 0;              // committed HCOMP registers (A is the input at every run; M and H: S.mreg / S.hreg, zeroed by the decoder)
+    c2_put0(&S.mb_ack, cmd);
+    uint32_t seq = 1;
+    bool alive = true;
+    while (alive) {
+      // ---- the first three bits of byte #seq
+      uint32_t v;
+      sp = 0;
+      while ((((v = c2_ld(&S.mb_nib)) >> 8) ^ seq) & 0xFFFFFFu) {   // (this one is on the clock; 24-bit sequence numbers)
+        if (c2_ld(&S.mb_cmd) != seen_cmd || ++sp > kC2Spin) { alive = false; break; }
+      }
+      if (!alive) break;
+      if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hb_t0)::"memory"); }
+      const uint32_t x = (v & 7u) << 5 | cand;
+      // ---- HCOMP for the candidates (both halves of the wave run it)
+      uint32_t sa = x, sb = hb, sc = hc, sd = hd, sf = hf;
+      uint32_t wi = 0, wv = 0, wn = 0, hs[NH], wmask = 0;
+#pragma unroll
+      for (uint32_t d = 0; d < NH; ++d) hs[d] = 0;
+      const SpecM sm{(lds_u8_p)lds_off(S.mreg), &wi, &wv, &wn};
+      const SpecH<NH> sh{(lds_u32_p)lds_off(S.hreg), hs, &wmask};
+      if constexpr (SP::id == 1) (void)zh_native_hcomp_min(sa, sb, sc, sd, sf, x, sm, (1u << SP::hm) - 1u, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
+      else (void)zh_native_hcomp_mid(sa, sb, sc, sd, sf, x, sm, (1u << SP::hm) - 1u, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
+      if (grp == 0) {
+#pragma unroll
+        for (uint32_t d = 0; d < NH; ++d) S.hspec[d][cand] = (uint32_t)sh[d];
+      }
+      // ---- rows of the first nibble of the next byte (c8 = 1): Predictor.find's three candidates per component
+      v4u rr[RN][3];
+      uint32_t cxts[RN];
+#pragma unroll
+      for (uint32_t r = 0; r < RN; ++r) {
+        uint32_t hval = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < NH; ++d) if ((u_comp[r] & (NH - 1u)) == d) hval = (uint32_t)sh[d];
+        const uint32_t cxt = hval + 16u;
+        cxts[r] = cxt;
+        const uint32_t h0 = (cxt * 16u) & (u_mask[r] - 15u);
+        const uint32_t vo = u_on[r] ? u_hto[r] + h0 : kOob;
+        rr[r][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 0);
+        rr[r][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo ^ 16u, 0, 0);
+        rr[r][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo ^ 32u, 0, 0);
+      }
+      // ---- mixer row for c8 = 1: weights grp, grp + 2, grp + 4, grp + 6 of the row of candidate `cand`
+      uint32_t mwv[4] = {0, 0, 0, 0};
+      if (SP::nmix) {
+        uint32_t hq = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < NH; ++d) if ((SP::mix_lane[0] & (NH - 1u)) == d) hq = (uint32_t)sh[d];
+        const uint32_t row = mx_base + ((hq + mx_c1) & mx_size1) * (SP::mix_m[0] * 4u);
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) {
+          const uint32_t jj = grp + 2u * t;
+          mwv[t] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, jj < SP::mix_m[0] ? row + jj * 4u : kOob, 0, 0);
+        }
+      }
+#pragma unroll
+      for (uint32_t r = 0; r < RN; ++r) {
+        if (u_on[r]) {
+          const uint32_t u = grp + 2u * r;
+#pragma unroll
+          for (uint32_t k = 0; k < 3; ++k) *(lds_u4_p)lds_off(&S.rowst[u][k][cand]) = rr[r][k];
+          // Predictor.find (Predictor.cs:550-567) on the three probes, here instead of at the decoder wave's byte boundary:
+          // check compare, then the lowest-priority row as the victim (ties as the reference breaks them)
+          const uint32_t chk = (cxts[r] >> u_sb2[r]) & 255u;
+          const uint32_t h0 = (cxts[r] * 16u) & (u_mask[r] - 15u);
+          const v4u &r0 = rr[r][0], &r1 = rr[r][1], &r2 = rr[r][2];
+          const bool m0 = (r0.x & 255u) == chk, m1 = (r1.x & 255u) == chk, m2 = (r2.x & 255u) == chk;
+          const uint32_t p0 = (r0.x >> 8) & 255u, p1 = (r1.x >> 8) & 255u, p2 = (r2.x >> 8) & 255u;
+          const uint32_t victim = (p0 <= p1 && p0 <= p2) ? h0 : p1 < p2 ? (h0 ^ 16u) : (h0 ^ 32u);
+          const uint32_t sel = m0 ? h0 : m1 ? (h0 ^ 16u) : m2 ? (h0 ^ 32u) : victim;
+          const v4u fresh = {chk, 0, 0, 0};
+          const v4u row = m0 ? r0 : m1 ? r1 : m2 ? r2 : fresh;
+          *(lds_u4_p)lds_off(&S.selrow[u][cand]) = row;
+          S.seloff[u][cand] = sel;
+        }
+      }
+      if (SP::nmix) {
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) S.mixst[cand][grp + 2u * t] = mwv[t];
+      }
+      asm volatile("" ::: "memory");
+      c2_put0(&S.mb_ready, seq);
+      if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hb_t1)::"memory"); hb_busy += hb_t1 - hb_t0; }
+      // ---- the byte: commit its candidate
+      sp = 0;
+      while ((((v = c2_ld(&S.mb_byte)) >> 8) ^ seq) & 0xFFFFFFu) {
+        if (c2_ld(&S.mb_cmd) != seen_cmd || ++sp > kC2Spin) { alive = false; break; }
+        __builtin_amdgcn_s_sleep(1);                     // (nothing to do until the byte is known: poll gently)
+      }
+      if (!alive) break;
+      if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hb_t0)::"memory"); hb_slack += hb_t0 - hb_t1; }
+      const uint32_t lo = v & (kNbCand - 1u);
+      hb = rdlane(sb, lo); hc = rdlane(sc, lo); hd = rdlane(sd, lo); hf = rdlane(sf, lo);
+      const uint32_t cwi = rdlane(wi, lo), cwv = rdlane(wv, lo), cwn = rdlane(wn, lo);
+      if (cwn && lane == 0) S.mreg[cwi] = (uint8_t)cwv;
+      if (lane < NH) { const uint32_t hv_ = S.hspec[lane][lo]; S.hreg[lane] = hv_; }
+      ++seq;
+    }
+  }
 }
 
 // ---- per-lane constants: the component this lane stands for and the path its group walks ----------------------------
@@ -171,7 +327,7 @@ __device__ __forceinline__ void nb_setup(NbK<SP> &K, LDS &S, const ZhModel *M, u
   K.pre[0] = 0; K.pre[1] = 0; K.pre[2] = K.b1; K.pre[3] = 2u * K.b1 + K.b2; K.pre[4] = 4u * K.b1 + 2u * K.b2 + K.b3;   // c8 of level d = (c8 of the nibble << (d-1)) + pre[d]
   K.ybit[0] = 0; K.ybit[1] = K.b1; K.ybit[2] = K.b2; K.ybit[3] = K.b3;     // the bit this group assumes at level d (d = 1..3)
   K.unit = (uint32_t)__builtin_popcountll(NbK<SP>::kII & ((1ull << K.ci) - 1));
-  K.un_ = K.unit < (uint32_t)kSpecUnits ? K.unit : 0u;
+  K.un_ = K.unit < c2_units<SP>() ? K.unit : 0u;
   const ZhComp *mycp = &M->comp[K.ci < SP::n ? K.ci : 0];
   K.hto = K.l_ii || K.l_match ? (uint32_t)mycp->ht_off : 0u; K.ht_mask = mycp->ht_mask;
   K.cmo = (uint32_t)mycp->cm_off; K.cm_mask = mycp->cm_mask;
@@ -454,6 +610,15 @@ __device__ __forceinline__ uint32_t nb_decode_byte(const NbK<SP> &K, NbV &V, LDS
         const int eq = __mul24(ey - sqm, K.mx_rate) >> 4;
         nmw[dd] = med3i(V.mwl[dd] + ((__mul24(eq, p) + rnd12) >> 13), -(1 << 19), (1 << 19) - 1);
       }
+      if (nib == 0 && dd == 3) {
+        // Three bits of the byte are known: the helper wave starts on the next byte's 32 candidates.  What its loads must see of
+        // this wave's stores (the rows written back at the last byte boundary, the mixer rows of the byte before) has reached
+        // memory: vector memory completes in issue order, and everything this wave has issued so far is waited for here (the
+        // youngest are the second nibble's candidate rows, requested a thousand cycles ago).  The rows written back later — at
+        // the nibble switch and at the byte boundary — are patched in from the copies kept here when the staging is taken.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        c2_put0(&S.mb_nib, bseq << 8 | (nv & 7u));
+      }
     }
     NB_STAMP(nib);
     // ---- commit: the group the nibble's first three bits name
@@ -485,7 +650,6 @@ __device__ __forceinline__ uint32_t nb_decode_byte(const NbK<SP> &K, NbV &V, LDS
       v4u old; uint32_t old_off, old_valid;
       nb_row_old(K, V, S, old, old_off, old_valid);
       V.old1 = old; V.old1_off = old_off; V.old1_valid = old_valid;
-      if (SP::nmix > 0) c2_put0(&S.mb_nib, bseq << 8 | (nv & 15u));       // (see zh_chain2.hip for what the helper's loads must see)
       const bool k1 = (nv & 1u) != 0;
       NbProbe pr;
       pr.h0 = k1 ? cand[1].h0 : cand[0].h0; pr.chk = k1 ? cand[1].chk : cand[0].chk;
@@ -506,7 +670,6 @@ __device__ __forceinline__ uint32_t nb_decode_byte(const NbK<SP> &K, NbV &V, LDS
         nb_row_take(K, V, rowb, selb);
         if (SP::nmix) { V.mwl[1] = K.l_feed ? (int)S.mixb[ci] : 0; nb_mix_rows(K, V, 16u + nv); }
       }
-      if (SP::nmix == 0) c2_put0(&S.mb_nib, bseq << 8 | (nv & 15u));      // min: after the rows requested at the byte's start were consumed
       if (SP::match_lane >= 0) nb_match_prefetch(K, V);
       NB_STAMP(4);
     } else cbyte = cbyte * 16u + nv;
@@ -527,11 +690,11 @@ __device__ __forceinline__ bool nb_boundary(const NbK<SP> &K, NbV &V, LDS &S, in
   }
   c2_put0(&S.mb_byte, bseq << 8 | (uint32_t)c);
   NB_STAMP(5);
-  const uint32_t lo = (uint32_t)c & 15u, un_ = K.un_;
+  const uint32_t lo = (uint32_t)c & (kNbCand - 1u), un_ = K.un_;
   auto read_staged = [&]() __attribute__((always_inline)) {
     V.hv = S.hspec[ci & ((1u << SP::hh) - 1u)][lo];
     sg_row = *(lds_u4_p)lds_off(&S.selrow[un_][lo]); sg_sel = S.seloff[un_][lo];
-    if (SP::nmix) { const uint32_t jj = ci - SP::mix_j0[0]; sg_mw = (int)S.mixst[0][lo][jj & 15u]; }
+    if (SP::nmix) { const uint32_t jj = ci - SP::mix_j0[0]; sg_mw = (int)S.mixst[lo][jj & 7u]; }
   };
   {
     const uint32_t rdy_v = __hip_atomic_load(&S.mb_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -747,7 +910,7 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
     if (lane == 0) { S.zrow = v4u_{0, 0, 0, 0}; S.mb_cmd = 0; S.mb_ack = 0; S.mb_nib = 0; S.mb_byte = 0; S.mb_ready = 0; }
   }
   __syncthreads();                                       // the only workgroup barrier of the kernel
-  if (!wave_a) { c2_helper<SP, LDS, PROF>(L, S, lane, blockIdx.x); return; }
+  if (!wave_a) { nb_helper<SP, LDS, PROF>(L, S, lane, blockIdx.x); return; }
   uint32_t cmd_seq = 0;
   for (uint32_t i = lane; i < 256; i += 64) {            // the two predictions of a match of length i
     const int dk = L.tables->dt2k[i];
