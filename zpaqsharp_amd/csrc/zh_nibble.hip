@@ -37,6 +37,7 @@ using namespace zhdev;
 #define C2_FINDB 1
 #include "zh_c2_common.h"
 #include "zh_nb_fast.h"
+#include "zh_nb_fast_mid.h"
 #ifndef ZH_NB_ASM
 #define ZH_NB_ASM 1                           /* 0: nb_fast runs the C++ form of its loop (A/B runs, the *_prof kernels) */
 #endif
@@ -72,8 +73,8 @@ struct alignas(16) NbLds {
   uint32_t mb_cmd, mb_ack, mb_model;
   uint32_t fxs[96];                           // nb_fast: scalars in and out (kFx*)
   uint32_t fxv[64][64];                       // ... and per-lane words (NbV, the coded chunk, the parked output)
-  uint32_t fxk[kNbK_count][64];               // zh_nb_fast.h: per-lane constants of the assembly loop
-  uint32_t fxa[kNbS_count + 12][64];          // ... and the per-lane state it loads and stores (+ the stamped variant's 12 sums)
+  uint32_t fxk[kNmK_count][64];               // zh_nb_fast*.h: per-lane constants of the assembly loop
+  uint32_t fxa[kNmS_count + 12][64];          // ... and the per-lane state it loads and stores (+ the stamped variant's 12 sums)
   uint32_t hreg[kHWords];
   uint8_t mreg[kMBytes];
   uint32_t r[256], pr[256];
@@ -791,11 +792,12 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
   const uint32_t klim = in.avail >= 40u ? in.avail - 40u : 0u;
   uint32_t vlo = (uint32_t)(uintptr_t)ob.base + (uint32_t)ob.len;     // low bits of the virtual output position
   uint32_t nput = 0, room = ob.room, word = ob.word;
-  if constexpr (SP::id == 1 && ZH_NB_ASM != 0) {
+  if constexpr ((SP::id == 1 || SP::id == 2) && ZH_NB_ASM != 0) {
     // ---- the loop in assembly (zh_nb_fast.h, tools/gen_nb_asm.py): constants and state through LDS
     if (lds_off(S.stretch) == 0 && V.rowvalid) {
       const uint32_t hmask_ = (1u << SP::hh) - 1u;
-      uint32_t kc[kNbK_count];
+      constexpr int kNK = SP::id == 2 ? (int)kNmK_count : (int)kNbK_count;
+      uint32_t kc[kNK];
       kc[kNbK_tab] = K.tab; kc[kNbK_slot] = K.wrow; kc[kNbK_wr2] = K.wrow + K.node[2]; kc[kNbK_wr3] = K.wrow + K.node[3]; kc[kNbK_wr4] = K.wrow + K.node[4];
       kc[kNbK_sh2] = K.sh2; kc[kNbK_sh3] = K.sh3; kc[kNbK_sh4] = K.sh4;
       kc[kNbK_ey1] = K.ybit[1] ? 32767u : 0u; kc[kNbK_ey2] = K.ybit[2] ? 32767u : 0u; kc[kNbK_ey3] = K.ybit[3] ? 32767u : 0u;
@@ -805,14 +807,32 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
       kc[kNbK_selrow] = lds_off(&S.selrow[K.un_][0]); kc[kNbK_seloff] = lds_off(&S.seloff[K.un_][0]);
       kc[kNbK_hspec] = lds_off(&S.hspec[K.ci & hmask_][0]); kc[kNbK_rowst] = lds_off(&S.rowst[K.un_][0][0]); kc[kNbK_slotoff] = lds_off(&S.slotoff[K.ci]);
       kc[kNbK_koob] = kOob; kc[kNbK_c2047] = 2047u; kc[kNbK_c512k] = (1u << 19) - 1u; kc[kNbK_rnd] = 1u << 12; kc[kNbK_c10000] = 0x10000u;
-      kc[kNbK_evo] = K.canon ? K.hto : kOob; kc[kNbK_mb] = lds_off(&S.mb_nib);
+      kc[kNbK_evo] = (K.canon && K.l_ii) ? K.hto : kOob; kc[kNbK_mb] = lds_off(&S.mb_nib);
+      if constexpr (SP::id == 2) {
+        constexpr uint32_t m4 = NbK<SP>::mx_m4;
+        kc[kNmK_rslot] = K.l_ii ? lds_off(&S.slot[K.ci]) : lds_off(&S.zrow);
+        kc[kNmK_rate] = (uint32_t)K.mx_rate; kc[kNmK_vomix] = K.vo_mix; kc[kNmK_cm0] = (16u + 2u * K.g) * m4;
+        kc[kNmK_row1_1] = (1u + K.pre[1]) * m4; kc[kNmK_row1_2] = (2u + K.pre[2]) * m4; kc[kNmK_row1_3] = (4u + K.pre[3]) * m4; kc[kNmK_row1_4] = (8u + K.pre[4]) * m4;
+        kc[kNmK_pre2] = K.pre[2] * m4; kc[kNmK_pre3] = K.pre[3] * m4; kc[kNmK_pre4] = K.pre[4] * m4;
+        kc[kNmK_lane1] = lane + 1u; kc[kNmK_htmask] = K.ht_mask; kc[kNmK_cmo] = K.cmo; kc[kNmK_cmmask] = K.cm_mask;
+        kc[kNmK_mixst] = lds_off(&S.mixst[0][K.ci & 7u]); kc[kNmK_mixb] = lds_off(&S.mixb[K.ci]);
+        kc[kNmK_evm] = (K.canon && K.l_match) ? 0u : kOob;
+      }
 #pragma unroll
-      for (int i = 0; i < kNbK_count; ++i) S.fxk[i][lane] = kc[i];
+      for (int i = 0; i < kNK; ++i) S.fxk[i][lane] = kc[i];
       S.fxa[kNbS_rx][lane] = V.row_x; S.fxa[kNbS_rq1][lane] = V.row_q1; S.fxa[kNbS_rq2][lane] = V.row_q2; S.fxa[kNbS_rq3][lane] = V.row_q3;
       S.fxa[kNbS_rowoff][lane] = V.rowoff; S.fxa[kNbS_hv][lane] = V.hv;
       S.fxa[kNbS_ob0][lane] = V.oldb.x; S.fxa[kNbS_ob1][lane] = V.oldb.y; S.fxa[kNbS_ob2][lane] = V.oldb.z; S.fxa[kNbS_ob3][lane] = V.oldb.w;
       S.fxa[kNbS_oboff][lane] = V.oldb_valid ? V.oldb_off : 0xFFFFFFFFu;       // (no row written back yet: a place no bucket has)
       S.fxa[kNbS_cur][lane] = in.cur;
+      if constexpr (SP::id == 2) {
+        S.fxa[kNmS_m_len][lane] = V.m_len; S.fxa[kNmS_m_ptr][lane] = V.m_ptr; S.fxa[kNmS_m_limit][lane] = V.m_limit; S.fxa[kNmS_m_byte][lane] = V.m_byte;
+        S.fxa[kNmS_pm0][lane] = (uint32_t)V.pm0; S.fxa[kNmS_pm1][lane] = (uint32_t)V.pm1; S.fxa[kNmS_cm_pre][lane] = V.cm_pre;
+        S.fxa[kNmS_va_pre][lane] = V.va_pre; S.fxa[kNmS_vb_pre][lane] = V.vb_pre; S.fxa[kNmS_mbn_pre][lane] = V.mbn_pre; S.fxa[kNmS_mbc_pre][lane] = V.mbc_pre;
+        S.fxa[kNmS_mx_rb][lane] = V.mx_rb; S.fxa[kNmS_w1_new][lane] = (uint32_t)V.w1_new;
+#pragma unroll
+        for (int dd = 1; dd <= 4; ++dd) { S.fxa[kNmS_mwl1 + dd - 1][lane] = (uint32_t)V.mwl[dd]; S.fxa[kNmS_mra1 + dd - 1][lane] = V.mrowl[dd]; }
+      }
       const uint64_t sm = (uint64_t)(uintptr_t)slot_mem;
       const v4u rs = {uni((uint32_t)sm), uni((uint32_t)(sm >> 32) & 0xffffu), uni((uint32_t)L.models[uni(S.fxs[kFxModel])].arena_bytes), 0x00020000u};
       const uint32_t kb = lds_off(&S.fxk[0][lane]), vb = lds_off(&S.fxa[0][lane]);
@@ -824,7 +844,15 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
         S.fxa[kNbS_park][lane] = ob.park;
         const uint32_t vlo_s = uni(vlo);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (PROF) {
+        if constexpr (SP::id == 2) {
+          const uint32_t mxb = uni(K.mx_base), mxs = uni(K.mx_size1), pmb = uni(lds_off(S.pm01));
+          if constexpr (PROF) {
+            ZH_NB_FAST_MID_LOOP_PROF(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb, mxb, mxs, pmb);
+            for (int i = 0; i < 12; ++i) P.prof[i] += S.fxa[kNmS_count + i][0];
+          } else {
+            ZH_NB_FAST_MID_LOOP(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb, mxb, mxs, pmb);
+          }
+        } else if constexpr (PROF) {
           ZH_NB_FAST_MIN_LOOP_PROF(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb);
           for (int i = 0; i < 12; ++i) P.prof[i] += S.fxa[kNbS_count + i][0];
         } else {
@@ -841,6 +869,14 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
       V.rowoff = S.fxa[kNbS_rowoff][lane]; V.hv = S.fxa[kNbS_hv][lane];
       V.oldb.x = S.fxa[kNbS_ob0][lane]; V.oldb.y = S.fxa[kNbS_ob1][lane]; V.oldb.z = S.fxa[kNbS_ob2][lane]; V.oldb.w = S.fxa[kNbS_ob3][lane];
       { const uint32_t oo = S.fxa[kNbS_oboff][lane]; V.oldb_valid = oo != 0xFFFFFFFFu; V.oldb_off = oo; }
+      if constexpr (SP::id == 2) {
+        V.m_len = S.fxa[kNmS_m_len][lane]; V.m_ptr = S.fxa[kNmS_m_ptr][lane]; V.m_limit = S.fxa[kNmS_m_limit][lane]; V.m_byte = S.fxa[kNmS_m_byte][lane];
+        V.pm0 = (int)S.fxa[kNmS_pm0][lane]; V.pm1 = (int)S.fxa[kNmS_pm1][lane]; V.cm_pre = S.fxa[kNmS_cm_pre][lane];
+        V.va_pre = S.fxa[kNmS_va_pre][lane]; V.vb_pre = S.fxa[kNmS_vb_pre][lane]; V.mbn_pre = S.fxa[kNmS_mbn_pre][lane]; V.mbc_pre = S.fxa[kNmS_mbc_pre][lane];
+        V.mx_rb = S.fxa[kNmS_mx_rb][lane]; V.w1_new = (int)S.fxa[kNmS_w1_new][lane];
+#pragma unroll
+        for (int dd = 1; dd <= 4; ++dd) { V.mwl[dd] = (int)S.fxa[kNmS_mwl1 + dd - 1][lane]; V.mrowl[dd] = S.fxa[kNmS_mra1 + dd - 1][lane]; }
+      }
       if (asm_why == 2) { why = 2; status = ofail ? (uint32_t)-24 : (uint32_t)ZH_E_CORRUPT; }
     }
   } else
