@@ -897,11 +897,19 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
           // ---- byte boundary: MATCH (Predictor.cs:391-410), HCOMP, h[], rows of the next byte
           {
             v4u sg_row = {0, 0, 0, 0}; uint32_t sg_sel = 0; int sg_mw[2] = {0, 0};   // what the helper wave staged for this byte's value
+            uint32_t ms_a1 = kOob, ms_a2 = kOob;         // MATCH's two stores of this byte: their places now, the stores themselves at ms_store()
             if (SP::match_lane >= 0) {                   // still with the h[i] of the byte just coded (update0 runs before z.run)
-              __builtin_amdgcn_raw_buffer_store_b8((uint8_t)c, rsrc, l_match ? hto + (m_limit & ht_mask) : kOob, 0, 0);
+              ms_a1 = l_match ? hto + (m_limit & ht_mask) : kOob;
               m_limit = l_match ? (m_limit + 1) & ht_mask : m_limit;
-              __builtin_amdgcn_raw_buffer_store_b32(m_limit, rsrc, l_match ? cmo + (hv & cm_mask) * 4u : kOob, 0, 0);   // (its old value: cm_pre)
+              ms_a2 = l_match ? cmo + (hv & cm_mask) * 4u : kOob;                                                     // (its old value: cm_pre)
             }
+            auto ms_store = [&]() __attribute__((always_inline)) {
+              if (SP::match_lane >= 0) {
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)c, rsrc, ms_a1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(m_limit, rsrc, ms_a2, 0, 0);
+              }
+            };
+            if (HELP == 1) ms_store();
             if (HELP) {
               // ---- two-wave form: the helper wave ran HCOMP for this byte's value among 16 (and staged what follows)
               c2_put0(&S.mb_byte, bseq << 8 | (uint32_t)c);
@@ -999,8 +1007,12 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             hv = lds_h[lane & hmask];
             }
             C2_STAMP(5);
-            v4u old; uint32_t old_off; bool old_valid;
-            row_evict(old, old_off, old_valid);
+            // (round 5) the row's write-back is issued BEHIND the next byte's loads: vector memory completes in issue order (one
+            // vmcnt for loads and stores), so rows_finish below, waiting for probes requested behind a store, also waited for
+            // that store's acknowledgement — at every byte boundary of the max model (profiles/r05/nb_stage_notes.txt)
+            v4u old = *(lds_u4_p)lds_off(&S.slot[lane]);
+            const uint32_t old_off = rowoff;
+            const bool old_valid = rowvalid && l_ii;
             Probe pr;
             rows_issue(1u, pr);
 #pragma unroll
@@ -1014,6 +1026,8 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               row20 = row20_load(1u);
               a19i = 1u; w19 = uni((uint32_t)S.a19[1]);
             }
+            if (HELP != 1) ms_store();                    // (behind the loads above, in front of the index load below)
+            __builtin_amdgcn_raw_buffer_store_b128(old, rsrc, old_valid ? hto + old_off : kOob, 0, 0);
             if (SP::match_lane >= 0) {
               match_boundary((uint32_t)c);
               cm_pre = __builtin_amdgcn_raw_buffer_load_b32(rsrc, l_match ? cmo + (hv & cm_mask) * 4u : kOob, 0, 0);
