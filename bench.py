@@ -119,7 +119,7 @@ def parse_args():
                          "writing 1 GiB with the max model takes the host cores minutes)")
     ap.add_argument("--schedule", default="lpt", help="N > 1: lpt (fixed shards, longest-first over estimated block costs) | "
                                                       "queue (ranks pull chunks from the shared work queue)")
-    ap.add_argument("--queue-blocks", type=int, default=256, help="--schedule queue: blocks per pull")
+    ap.add_argument("--queue-blocks", type=int, default=0, help="--schedule queue: blocks per pull (0: multigpu.default_queue_blocks)")
     ap.add_argument("--gen-threads", type=int, default=None)
     ap.add_argument("--kernel", type=int, default=0, help="zpaqhip_opts.kernel (0 auto; 5 = round-1 chain kernels for min/mid/max)")
     ap.add_argument("--cache-dir", default=None, help="keep generated streams here and reuse them (profiling runs)")
@@ -609,7 +609,7 @@ def main():
                         f"model {model_name} ({model.n} component(s)), plaintext generator {kind}",
             "zpaq_model": model_name, "blocks_per_gpu": nb, "block_bytes": bs, "plaintext": kind,
             "coded_over_plain": round(rho, 4),
-            "parallelism": ((f"blocks x{world}: shared stream, broadcast table, work queue (chunks of {args.queue_blocks} cost-ordered blocks, "
+            "parallelism": ((f"blocks x{world}: shared stream, broadcast table, work queue (chunks of {getattr(job, 'queue_blocks', args.queue_blocks)} cost-ordered blocks, "
                              f"one counter on the job's store), all_gather of results" if dynamic else
                              f"blocks x{world}: shared stream, broadcast table, LPT plan over estimated block costs, ids-sharded HIP decode, "
                              f"all_gather of results") if world > 1 else "blocks x1"),

@@ -128,8 +128,9 @@ typedef struct zpaqhip_opts {
                                  0 = default (1<<32).  Exceeding it ends the block with ZPAQHIP_E_BUDGET */
   uint64_t batch_blocks;      /* whole-stream forms: blocks per pipeline batch; 0 = default (at least 512 blocks and 32 MiB
                                  of coded bytes per batch, so that every CU has a block) */
-  uint64_t queue_blocks;      /* zpaqhip_decompress_multi: blocks per pull from the shared work queue; 0 = default (256: one
-                                 block per CU of the device that takes the chunk) */
+  uint64_t queue_blocks;      /* zpaqhip_decompress_multi: blocks per pull from the shared work queue; 0 = default: 256 (one block per
+                                 CU of the device that takes the chunk; 512 where every block is a single-CM one), but no more than a
+                                 quarter of a device's share of the blocks, so that every device pulls at least four times */
   uint64_t reserved[2];
 } zpaqhip_opts;
 

@@ -647,7 +647,7 @@ struct Sinkk {
   std::vector<std::vector<uint8_t>> *spill = nullptr;
 };
 
-constexpr size_t kBatchMinBlocks = 512, kBatchMinBytes = 32u << 20, kBatchMaxBlocks = 4096;   // 512: single-CM blocks run two per CU (zh_decode_cm_x2); the other kernels take the batch in two rounds of their work queue
+constexpr size_t kBatchMinBlocks = 512, kBatchMinBlocksOther = 256, kBatchMinBytes = 32u << 20, kBatchMaxBlocks = 4096;   // 512: single-CM blocks run two per CU (zh_decode_cm_x2); every other kernel holds 256 blocks per launch, and a second batch overlaps its copies with this one's kernels
 constexpr size_t kReadChunk = 4u << 20, kPinChunk = 32u << 20;
 
 // A header the framing scan accepts can still be refused when the model is built (component limits, table sizes:
@@ -683,8 +683,8 @@ void cut_at_bad_model(Batch &bt) {
 // Next batch of whole blocks, or batch.so.blocks.empty() at the end of the stream.  Returns a call-level error only.
 int next_batch(Source &src, Batch &bt, size_t blk0, size_t seg0, size_t batch_blocks, zpaqhip_err *err) {
   ScanLimit lim;
-  lim.min_blocks = kBatchMinBlocks; lim.min_bytes = kBatchMinBytes; lim.max_blocks = kBatchMaxBlocks;
-  if (batch_blocks) { lim.min_blocks = lim.max_blocks = batch_blocks; lim.min_bytes = 0; }   // zpaqhip_opts.batch_blocks
+  lim.min_blocks = kBatchMinBlocks; lim.min_blocks_other = kBatchMinBlocksOther; lim.min_bytes = kBatchMinBytes; lim.max_blocks = kBatchMaxBlocks;
+  if (batch_blocks) { lim.min_blocks = lim.max_blocks = batch_blocks; lim.min_blocks_other = 0; lim.min_bytes = 0; }   // zpaqhip_opts.batch_blocks
   bt = Batch();
   bt.blk0 = blk0; bt.seg0 = seg0;
   zpaqhip_err e2{};
@@ -1178,7 +1178,7 @@ int zpaqhip_block_costs(const uint8_t *in, size_t in_len, const zpaqhip_block *b
         // estimates for the fallback kernels
         w = fam == ZH_FAM_STORE ? (pcomp ? 120u : 30u)                // zh_store.hip: wave-wide copy / LZ77 / inverse BWT
             : fam == ZH_FAM_CM1 ? kCm1Marker                         // zh_cm.hip: by coded / plain ratio, below
-            : fam == ZH_FAM_CHAIN + 1 ? 6200u : fam == ZH_FAM_CHAIN + 2 ? 9200u : fam == ZH_FAM_CHAIN + 3 ? 17300u   // zh_chain2.hip min / mid / max
+            : fam == ZH_FAM_CHAIN + 1 ? 3800u : fam == ZH_FAM_CHAIN + 2 ? 6800u : fam == ZH_FAM_CHAIN + 3 ? 16600u   // zh_nibble.hip min / mid, zh_chain2.hip max (profiles/r05)
             : fam == ZH_FAM_CHAIN ? 4000u + 2200u * m.n               // zh_chain.hip: level walk at run time
             : 10000u + 16000u * m.n;                                  // zh_generic.hip: one lane, tables in HBM
         if (pcomp && fam != ZH_FAM_STORE) w += w == kCm1Marker ? (uint64_t)-1 : 1500u;       // (marker - 1: single CM with a post-processor)
@@ -1194,10 +1194,10 @@ int zpaqhip_block_costs(const uint8_t *in, size_t in_len, const zpaqhip_block *b
       const uint64_t pp = w == kCm1Marker ? 0u : 1500u;
       // zh_cm.hip: the byte loop costs the same on any data, a window miss ~1 400 cycles more, and the miss rate of an
       // order-1 context follows the data's entropy — which the block shows as coded / plain.  Measured at 256 blocks per GPU
-      // (profiles/r04): text 0.45 -> 1 080 cycles per byte, x86-like 0.75 -> 1 410, random 1.03 -> 2 200; piecewise linear
+      // (profiles/r04): text 0.45 -> 920 cycles per byte, x86-like 0.75 -> 1 250, random 1.03 -> 2 020; piecewise linear
       // between them (a block without a size hint counts as text)
       const double rho = hinted && plain ? (double)coded / (double)plain : 0.45;
-      w = pp + (rho <= 0.45 ? 1100u : rho <= 0.75 ? 1100u + (uint64_t)((rho - 0.45) * 1030.0) : 1410u + (uint64_t)((std::min(rho, 1.1) - 0.75) * 2820.0));
+      w = pp + (rho <= 0.45 ? 920u : rho <= 0.75 ? 920u + (uint64_t)((rho - 0.45) * 1100.0) : 1250u + (uint64_t)((std::min(rho, 1.1) - 0.75) * 2750.0));
     }
     cost[b] = std::max<uint64_t>(1, plain) * w;
   }
@@ -1247,7 +1247,7 @@ extern "C" void zpaqhip_multi_trim(void) {
 // Several GPUs of one node: one context and one host thread per entry of `devices`, all pulling from ONE work queue.
 //   queue   the blocks sorted by estimated cost (zpaqhip_block_costs) are dealt into K = ceil(n / queue_blocks) chunks,
 //           chunk k = every K-th block of that order starting at k (each chunk is a cross-section of the cost
-//           distribution and fills a GPU: queue_blocks defaults to 256, one block per CU); a device thread takes the
+//           distribution; queue_blocks defaults to min(256 — one block per CU —, a quarter of a device's share)); a device thread takes the
 //           next chunk (one atomic counter) whenever it has finished one, so a GPU that is faster, or whose chunks
 //           turned out cheaper than estimated, simply takes more of them
 //   placing block b goes to out + (sum of the plausible comment sizes before it); a block whose comment carries no
@@ -1260,7 +1260,6 @@ int zpaqhip_decompress_multi_stats(const int *devices, size_t n_dev, const uint8
                                    size_t *out_len, const zpaqhip_opts *opts_in, zpaqhip_stats *per_device, zpaqhip_err *err) {
   if (!devices || !n_dev || (!in && in_len) || !out_len || (!out && out_cap)) { set_err(err, ZPAQHIP_E_ARG, -1, -1); return ZPAQHIP_E_ARG; }
   zpaqhip_opts opts = resolve_opts(opts_in);
-  const size_t chunk_blocks = opts.queue_blocks ? (size_t)opts.queue_blocks : 256;
   *out_len = 0;
   if (per_device) memset(per_device, 0, n_dev * sizeof(zpaqhip_stats));
   ScanOut so;
@@ -1274,6 +1273,16 @@ int zpaqhip_decompress_multi_stats(const int *devices, size_t n_dev, const uint8
   std::vector<size_t> order(nb);
   std::iota(order.begin(), order.end(), (size_t)0);
   std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+  // blocks per pull: what the caller says, or a chunk that fills a GPU (256: one block per CU; 512 where every block is a
+  // single-CM one: two per CU) — but at least four pulls per device, or the queue has nothing to rebalance with
+  // (multigpu.default_queue_blocks is the same rule)
+  size_t chunk_blocks = (size_t)opts.queue_blocks;
+  if (!chunk_blocks) {
+    bool all_cm1 = true;
+    for (size_t b = 0; b < nb; ++b) all_cm1 = all_cm1 && so.blocks[b].n_comp == 1;
+    const size_t full = all_cm1 ? 512 : 256, per4 = (nb + 4 * n_dev - 1) / (4 * n_dev);
+    chunk_blocks = std::max<size_t>(1, std::min(full, per4));
+  }
   const size_t K = (nb + chunk_blocks - 1) / chunk_blocks;
   std::atomic<size_t> next_chunk{0};
   std::atomic<bool> abort_all{false};

@@ -314,7 +314,6 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       }
       if (!alive) break;
       if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hb_t0)::"memory"); }
-      asm volatile("" ::"v"(touch_a), "v"(touch_b[0]), "v"(touch_b[1]), "v"(touch_b[2]), "v"(touch_b[3]), "v"(touch_b[4]), "v"(touch_b[5]));   // the touches of the byte before are long back
       const uint32_t x = (v & 15u) << 4 | cand;
       // ---- HCOMP for the candidates (all 64 lanes run it: four copies of each candidate)
       uint32_t sa = x, sb = hb, sc = hc, sd = hd, sf = hf;
@@ -371,16 +370,6 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
           mwv[q][t] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, jj < SP::mix_m[q] ? row + jj * 4u : kOob, 0, 0);
         }
       }
-#ifdef C2_TOUCH
-      if (C2_TOUCH && SP::nmix > 0 && !LDS::kMixLds) {
-        // lines 0-3 of the block of mixer rows each candidate byte leads to (rows 1-15: what bits 0-3 of the next byte
-        // read); the rest of the winner's block is touched at the commit below.  The values are dropped, late.
-        uint32_t hq = 0;
-#pragma unroll
-        for (uint32_t d = 0; d < NH; ++d) if ((SP::mix_lane[0] & (NH - 1u)) == d) hq = (uint32_t)sh[d];
-        touch_a = __builtin_amdgcn_raw_buffer_load_b32(rsrc, mx_base[0] + (hq & mx_size1[0] & ~255u) * (SP::mix_m[0] * 4u) + grp * 128u, 0, 0);
-      }
-#endif
 #pragma unroll
       for (uint32_t r = 0; r < 2; ++r) {
         if (u_on[r]) {
@@ -452,27 +441,6 @@ __device__ void c2_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       const uint32_t cwi = rdlane(wi, lo), cwv = rdlane(wv, lo), cwn = rdlane(wn, lo);
       if (cwn && lane == 0) S.mreg[cwi] = (uint8_t)cwv;
       if (lane < NH) { const uint32_t hv_ = S.hspec[lane][lo]; S.hreg[lane] = hv_; }
-#ifdef C2_TOUCH
-      if (C2_TOUCH && SP::nmix > 0 && !LDS::kMixLds) {
-        // the byte is known, so is the block of 255 mixer rows the next byte walks (a new 128-byte line with almost every
-        // bit): one dword per line and lane now, and the decoder wave's one-bit-ahead requests find the lines in L2
-        const uint32_t hq = S.hspec[SP::mix_lane[0] & (NH - 1u)][lo];
-        const uint32_t b0 = mx_base[0] + (hq & mx_size1[0] & ~255u) * (SP::mix_m[0] * 4u);
-        constexpr uint32_t kBlk = 256u * SP::mix_m[0] * 4u;
-#pragma unroll
-        for (uint32_t t = 0; t < 2; ++t)
-          if (t * 8192u < kBlk) touch_b[t] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 128u + t * 8192u < kBlk ? b0 + lane * 128u + t * 8192u : kOob, 0, 0);
-        if constexpr (SP::has_tail) {                   // max: the 256 rows of `sse 16 19` under h[20] (32 entries = one line each)
-          const ZhComp &sc20 = M->comp[20];
-          const uint32_t h20 = S.hspec[20][lo];
-#pragma unroll
-          for (uint32_t t = 0; t < 4; ++t) {
-            const uint32_t r = (((h20 + lane + 64u * t) * 32u) & sc20.cm_mask) * 4u + (uint32_t)sc20.cm_off;
-            touch_b[2 + t] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, r, 0, 0);
-          }
-        }
-      }
-#endif
       if constexpr (LDS::kMixLds) {
         // the block of mixer rows the NEXT byte uses (its context is known now) -> the other half of mixblk; a byte
         // that keeps the context keeps the block, which the decoder wave has kept up to date

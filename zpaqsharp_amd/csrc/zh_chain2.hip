@@ -38,20 +38,15 @@ using namespace zhdev;
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 
 // Build-time variants for same-box A/B runs (tools/ab_bench.sh, tools/build_variants.sh): -DC2V=<mask>.  The shipped build is
-// everything but 8 (mid +0.6 %, max +1 % — for 3.5 TB / 21 TB more HBM reads per GiB: bytes that buy that little are not spent)
-// and 16 (measured slower); 32 for the max model only (profiles/r04/ab_notes.txt): 999.
+// 999: every bit below; 32 for the max model only (profiles/r04/ab_notes.txt).  (Round 4's variants 8 — the helper wave touching
+// the lines of the mixer rows ahead: mid +0.6 %, max +1 % for 3.5 TB / 21 TB more HBM reads per GiB — and 16 — a one-way entry
+// fetch: fewer instructions, slower — were measured, not shipped, and are gone from the source: profiles/r04/ab_notes.txt.)
 //   1  the decoder step hands y to the vector side itself (select mask, ey, y made under the split's SCC: ZH_DEC_STEP_Y)
 //   2  what a bit trains but the NEXT bit cannot read — mixer weights (their row changes with every bit), max's SSE entries
 //      and `mix2 8` weight — is computed one bit later, in the shadow of that bit's squash look-up (an s_load or ds_read
 //      round trip during which round 3's wave issued nothing)
 //   4  the hash row of the nibble stays in four VGPRs: the bit histories of the next bit's two candidate nodes are bit
 //      fields of a register, not an LDS read in front of the entry reads
-//   8  the helper wave touches the lines of the mixer rows (and max's `sse 16` rows) a byte can reach before the decoder
-//      wave asks for them (zh_c2_common.h): the per-bit weight loads, requested one bit ahead, then hit L2 (~200 cycles)
-//      instead of HBM (~900) — round 4's stamps found the decoder wave waiting ~200 cycles per bit for them in mid
-//  16  (with 4) ONE-way entry fetch: the next bit's entry is read right after the bit is decoded (its state is a bit field of
-//      the row registers, its address one v_lshl_add) and comes back under the update's ~35 instructions; round 2/3 read
-//      both candidates before the bit was known and selected: 13 instructions against 6
 //  32  MATCH's prediction as pm0 + bit * (pm1 - pm0) and a miss resetting it to the lane's constant: 7 instructions for 10
 //  64  the 12 hash-row requests of the second nibble's candidates go out BEHIND the mixer weights of bit 3 instead of in front
 //      of them: vector memory returns in issue order, and round 4's per-bit stamps show mid's bit 2 waiting ~360 cycles for
@@ -70,7 +65,6 @@ using namespace zhdev;
 #ifndef C2V
 #define C2V 999
 #endif
-#define C2_TOUCH ((C2V & 8) != 0)
 #define C2_FINDB ((C2V & 256) != 0)
 #define C2_SPECRD ((C2V & 512) != 0)
 
@@ -97,7 +91,8 @@ namespace {
 
 __device__ __forceinline__ void c2_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }   // one wave: no barrier
 // scalar x vector 24-bit multiply, by hand: where the compiler can prove that a 24-bit multiply equals the 32-bit one it
-// selects v_mul_lo_u32 for an SGPR x VGPR product — a quarter-rate instruction
+// selects v_mul_lo_u32 (+ narrowing moves) for an SGPR x VGPR product; the 24-bit form is one instruction (a dependent
+// v_mul_lo_u32 chain issues at the rate of v_add_u32 on a lone gfx950 wave: tools/ubench/exec_bench — the gain is the count)
 __device__ __forceinline__ int mul24_sv(int sc, int vec) {
   int r;
   asm("v_mul_i32_i24_e32 %0, %1, %2" : "=v"(r) : "s"(sc), "v"(vec));
@@ -106,7 +101,7 @@ __device__ __forceinline__ int mul24_sv(int sc, int vec) {
 
 
 constexpr bool kYsel = (C2V & 1) != 0, kDefer = (C2V & 2) != 0, kRowReg = (C2V & 4) != 0;
-constexpr bool kOneWay = (C2V & 16) != 0 && kRowReg, kRowsLate = (C2V & 64) != 0, kFar2 = (C2V & 128) != 0 && kYsel;
+constexpr bool kRowsLate = (C2V & 64) != 0, kFar2 = (C2V & 128) != 0 && kYsel;
 
 template <class SP, bool PROF, int HELP, class LDS>
 __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
@@ -446,7 +441,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
     uint32_t mx_h[2] = {0, 0}, mx_rb[2] = {0, 0};        // h[] of the mixer components; this lane's buffer offset in row 0 of the byte
     auto mix_set = [&](uint32_t q, uint32_t hq) __attribute__((always_inline)) {
       mx_h[q] = uni(hq);
-      mx_rb[q] = vo_mix[q] + (mx_base[q] + __umul24(mx_h[q] & mx_size1[q] & ~255u, mx_m4[q]));   // < 2^16 x < 2^8: 24-bit multiplies are full rate
+      mx_rb[q] = vo_mix[q] + (mx_base[q] + __umul24(mx_h[q] & mx_size1[q] & ~255u, mx_m4[q]));   // < 2^16 x < 2^8: exact in 24 bits
     };
     // The row's place is a per-lane buffer offset (lane's weight inside the row + row): all of it vector arithmetic, so that
     // no value has to cross from the vector to the scalar unit on the way to the load (round 2 kept the row part in an SGPR:
@@ -587,7 +582,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             if (SP::match_lane >= 0 && bit == 4) match_prefetch();
             uint32_t ea0 = 0, ea1 = 0, st0 = 0, st1 = 0;
             v2u e0 = {0, 0}, e1 = e0;
-            if (pre_ii && !kOneWay) {
+            if (pre_ii) {
               if (kRowReg) {
                 // nodes 2hm, 2hm+1: bytes of the row held in registers (hm = 1: bytes 2, 3; hm = 2, 3: dword 1; hm = 4..7: dword 2 / 3)
                 const uint32_t x = (bit & 3) == 0 ? row_x : (bit & 3) == 1 ? row_q1 : rzw;
@@ -604,8 +599,8 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             if (pre_mx) {
 #pragma unroll
               for (uint32_t q = 0; q < SP::nmix; ++q) {
-                // c8 < 128 here (no mask); v_mad_u32_u24 by hand: the compiler turns this into v_mad_u64_u32, a quarter-rate
-                // instruction, whatever the source says about the operands' width
+                // c8 < 128 here (no mask); v_mad_u32_u24 by hand: the compiler turns this into v_mad_u64_u32 and narrowing moves,
+                // whatever the source says about the operands' width
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(mrow0[q]) : "s"(c8), "v"(SP::mix_m[q] * 8u), "v"(mx_rb[q]));
                 mrow1[q] = mrow0[q] + SP::mix_m[q] * 4u;
                 if (!(far2 && bit >= 5)) {               // (bits 6 and 7: requested two bits ago)
@@ -640,7 +635,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             const int cw0 = (int)eA & isse_m;
             const int cw1m = (int)((uint32_t)x << cshift);
             int p = x;
-            if (pre_ii && !kOneWay) {                    // second half of (a): the two entries (their addresses came back)
+            if (pre_ii) {                    // second half of (a): the two entries (their addresses came back)
               if (!kRowReg) { st0 = pairS & 255u; st1 = pairS >> 8; }
               ea0 = tab + st0 * 8u;
               ea1 = tab + st1 * 8u;
@@ -759,18 +754,6 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             const int ey = (int)ey_s;
             auto pick = [&](uint32_t a0, uint32_t a1) __attribute__((always_inline)) -> uint32_t { return kYsel ? sel_y(a0, a1, ym) : (y ? a1 : a0); };
             C2_STAMP(2);
-            uint32_t nea1 = 0, st_n1 = 0;
-            v2u en1 = {0, 0};
-            if (kOneWay && pre_ii) {
-              // the next bit's node is 2hm + y: its bit-history state is byte (2 + y | 2 y' + y) of the row dword for this depth;
-              // the entry it selects is requested NOW (before this bit's entry is written back: the `same` test below serves
-              // that case from registers) and travels under the update
-              const uint32_t xr_ = (bit & 3) == 0 ? row_x : (bit & 3) == 1 ? row_q1 : rzw;
-              const uint32_t sh = ((bit & 3) == 0 ? 16u : y_prev * 16u) + y * 8u;
-              st_n1 = __builtin_amdgcn_ubfe(xr_, sh, 8u);
-              nea1 = tab + st_n1 * 8u;
-              en1 = *(lds_u2_p)nea1;
-            }
             // ---- (e) update (Predictor.cs:363-461)
             const int e = ey - sqp;
             // bit history of this node: next(state, y) -> row byte
@@ -833,15 +816,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
               row20 = row20n;
               w19 = pick(w19n0, w19n1); a19i = c8 & 255u;
             }
-            if (pre_ii && kOneWay) {
-              hm = hm * 2u + y;
-              const bool same = nea1 == ea;              // bit k trained the entry bit k+1 predicts from
-              st = st_n1;
-              eA = same ? nA : en1.x;
-              eB = same ? nB : en1.y;
-              ea = nea1;
-              if ((bit & 3) == 0) rzw = pick(row_q2, row_q3);
-            } else if (pre_ii) {
+            if (pre_ii) {
               hm = hm * 2u + y;
               const uint32_t nea = pick(ea0, ea1);
               const bool same = nea == ea;               // bit k trained the entry bit k+1 predicts from

@@ -284,21 +284,9 @@
 #define ZH_STR_(x) #x
 #define ZH_STR(x) ZH_STR_(x)
 #define ZH_FAST_PAD ".fill " ZH_STR(ZH_L1_PAD) ", 4, 0xbf800000\n"
-#define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_, thr_, nm_, mqa_, kb_) \
-  asm volatile(                                                       \
-  "v_mov_b32_e32 v249, 0\n\t"                                         \
-  ZH_FAST_ENTRY                                                       \
-  ZH_FAST_LAGV                                                        \
-  "s_branch .Lzh_byte_%=\n\t"   /* over the alignment padding: up to 63 s_nop, ~150 cycles per entry on average, and a window miss enters anew */ \
-  ".p2align 8\n"                                                      \
-  ZH_FAST_PAD                                                         \
-  ".Lzh_byte_%=:\n\t"                                                 \
-  ZH_CM_FAST_BYTE(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, "", "", "", "")       \
-  ZH_CM_FAST_BYTE(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, "", "", "", "") \
-  "s_branch .Lzh_byte_%=\n"                                           \
-  /* ---- out of line ---- */                                         \
-  ZH_CM_FAST_COLD(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, "", ZH_FAST_OK_DIRECT)               \
-  ZH_CM_FAST_COLD(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, "", ZH_FAST_OK_DIRECT)      \
+// The window miss, served inside the loop: ONE definition for the product loop and the stamped diagnostic loop below (a fix in
+// one copy used to diverge the stage tables from the product)
+#define ZH_FAST_MISS_BLOCK                                            \
   /* ---- window miss, served without leaving the loop (round 4: the stage table of a miss, profiles/r04/stages_l1_miss_before.txt, \
      showed ~1 000 of its ~3 000 cycles between leaving this loop and re-entering it, and most of the rest waiting for wave B to \
      finish the byte before).  Victim = the first slot not used since message `thr` (empty slots carry 0, lanes that stand for no \
@@ -349,7 +337,23 @@
   "s_sub_u32 s80, s80, 1\n\t"                                         \
   "s_cmp_lg_u32 s80, 0\n\t"                                           \
   "s_cbranch_scc1 .Lzh_mspin_%=\n\t"                                  \
-  "s_branch .Lzh_slow_%=\n"                                           \
+  "s_branch .Lzh_slow_%=\n"
+#define ZH_CM_FAST_LOOP(low_, high_, curr_, k_, t_, h0_, bdone_, lu_, code_, klim_, bfe_, hs_, vr_, vm_, bsa_, cur_, tag_, la_, lb_, thr_, nm_, mqa_, kb_) \
+  asm volatile(                                                       \
+  "v_mov_b32_e32 v249, 0\n\t"                                         \
+  ZH_FAST_ENTRY                                                       \
+  ZH_FAST_LAGV                                                        \
+  "s_branch .Lzh_byte_%=\n\t"   /* over the alignment padding: up to 63 s_nop, ~150 cycles per entry on average, and a window miss enters anew */ \
+  ".p2align 8\n"                                                      \
+  ZH_FAST_PAD                                                         \
+  ".Lzh_byte_%=:\n\t"                                                 \
+  ZH_CM_FAST_BYTE(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, "", "", "", "")       \
+  ZH_CM_FAST_BYTE(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, "", "", "", "") \
+  "s_branch .Lzh_byte_%=\n"                                           \
+  /* ---- out of line ---- */                                         \
+  ZH_CM_FAST_COLD(a, 0, 1, 2, 3, 4, 5, 6, 7, 8, "", ZH_FAST_OK_DIRECT)               \
+  ZH_CM_FAST_COLD(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, "", ZH_FAST_OK_DIRECT)      \
+  ZH_FAST_MISS_BLOCK                                                  \
   ".Lzh_corrupt_%=:\n\t"                                              \
   "s_mov_b32 %[code], 1\n\t"                                          \
   "s_branch .Lzh_end_%=\n"                                            \
@@ -436,57 +440,7 @@
   ZH_CM_FAST_COLD(b, 10, 11, 12, 13, 14, 15, 16, 17, 18, ZH_PROF_SPIN_IN, ZH_PROF_SPIN_OKL)     \
   ZH_PROF_SPIN_OKB(a)                                                 \
   ZH_PROF_SPIN_OKB(b)                                                 \
-  /* ---- window miss, served without leaving the loop (round 4: the stage table of a miss, profiles/r04/stages_l1_miss_before.txt, \
-     showed ~1 000 of its ~3 000 cycles between leaving this loop and re-entering it, and most of the rest waiting for wave B to \
-     finish the byte before).  Victim = the first slot not used since message `thr` (empty slots carry 0, lanes that stand for no \
-     slot ~0); the directory is updated here and the swap wave (wave C, zh_cm.hip) gets victim, window and slot through three LDS \
-     words — every lane writes the same value to the same word: no exec switch —; the wave spins on C's answer and starts the \
-     byte over: the lookup then hits.  The fresh window is stamped as if used 13 messages ago: nothing of it is outstanding with \
-     wave B, 13 is what the ring can hold.  No candidate, or a window id beyond 16 bits: the C++ body serves it. */ \
-  ZH_FAST_COLD_ALIGN                                                  \
-  ".Lzh_miss_%=:\n\t"                                                 \
-  ZH_FAST_T                                                           \
-  "s_cmp_ge_u32 s81, 0x10000\n\t"                                     \
-  "s_cbranch_scc1 .Lzh_slow_%=\n\t"                                   \
-  "v_cmp_gt_u32_e32 vcc, %[thr], %[lu]\n\t"                           \
-  "s_cbranch_vccnz .Lzh_mvic_%=\n\t"                                  \
-  /* no slot that old: the threshold moves up to kb messages ago (pick_victim in zh_cm.hip is the same rule) */ \
-  "s_sub_u32 %[thr], %[t], %[kb]\n\t"                                 \
-  "s_max_i32 %[thr], %[thr], 1\n\t"                                   \
-  "v_cmp_gt_u32_e32 vcc, %[thr], %[lu]\n\t"                           \
-  "s_cbranch_vccz .Lzh_slow_%=\n"                                     \
-  ".Lzh_mvic_%=:\n\t"                                                 \
-  "s_ff1_i32_b64 s82, vcc\n\t"                                        \
-  "s_mov_b32 s84, m0\n\t"                                             \
-  "s_mov_b32 m0, s82\n\t"                                             \
-  "s_add_u32 %[nm], %[nm], 1\n\t"                                     \
-  "s_and_b32 s85, %[nm], 0xff\n\t"                                    \
-  "s_lshl_b32 s80, s85, 23\n\t"                                       \
-  "s_lshl_b32 s86, s81, 6\n\t"                                        \
-  "s_or_b32 s80, s80, s86\n\t"                                        \
-  "s_or_b32 s80, s80, s82\n\t"                                        \
-  "v_readlane_b32 s83, %[tag], m0\n\t"                                \
-  "v_writelane_b32 %[tag], s81, m0\n\t"                               \
-  "v_mov_b32_e32 v250, s83\n\t"                                       \
-  "ds_write_b32 %[mqa], v250 offset:4\n\t"                            \
-  "v_mov_b32_e32 v250, s80\n\t"                                       \
-  "ds_write_b32 %[mqa], v250\n\t"                                     \
-  "s_sub_u32 s87, %[t], 13\n\t"                                       \
-  "s_max_i32 s87, s87, 1\n\t"                                         \
-  "v_writelane_b32 %[lu], s87, m0\n\t"                                \
-  ZH_FAST_LAGV                                                        \
-  "s_mov_b32 m0, s84\n\t"                                             \
-  "s_mov_b32 s80, 0x4000\n"                                           \
-  ".Lzh_mspin_%=:\n\t"                                                \
-  "ds_read_b32 v252, %[mqa] offset:8\n\t"                             \
-  "s_waitcnt lgkmcnt(0)\n\t"                                          \
-  "v_readfirstlane_b32 s86, v252\n\t"                                 \
-  "s_cmp_eq_u32 s86, s85\n\t"                                         \
-  "s_cbranch_scc1 .Lzh_byte_%=\n\t"                                   \
-  "s_sub_u32 s80, s80, 1\n\t"                                         \
-  "s_cmp_lg_u32 s80, 0\n\t"                                           \
-  "s_cbranch_scc1 .Lzh_mspin_%=\n\t"                                  \
-  "s_branch .Lzh_slow_%=\n"                                           \
+  ZH_FAST_MISS_BLOCK                                                  \
   ".Lzh_corrupt_%=:\n\t"                                              \
   "s_mov_b32 %[code], 1\n\t"                                          \
   "s_branch .Lzh_end_%=\n"                                            \

@@ -172,9 +172,12 @@ int scan_stream(const uint8_t *in, size_t n, ScanOut &out, zpaqhip_err *err, con
 }
 
 static int scan_blocks(Cur &c, const uint8_t *in, ScanOut &out, zpaqhip_err *err, const ScanLimit &lim) {
+  bool single_only = true;                               // every block so far has one component (the single-CM kernel's two-per-CU form)
   for (;;) {
+    if (!out.blocks.empty() && out.blocks.back().n_comp != 1) single_only = false;
+    const size_t min_blocks = (lim.min_blocks_other && !single_only) ? lim.min_blocks_other : lim.min_blocks;
     if (!out.blocks.empty() &&
-        (out.blocks.size() >= lim.max_blocks || (out.blocks.size() >= lim.min_blocks && out.blocks.back().end_off >= lim.min_bytes))) {
+        (out.blocks.size() >= lim.max_blocks || (out.blocks.size() >= min_blocks && out.blocks.back().end_off >= lim.min_bytes))) {
       out.stopped = true;                                // a batch is complete: the caller continues from resume_off
       return ZPAQHIP_OK;
     }
@@ -448,7 +451,10 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
   // the family chosen above.
   if (m.n == 1 && m.comp[0].type == ZH_CM && m.comp[0].arg[0] >= 9) {
     const uint8_t *hc = hdr + cp;
-    if (m.hcomp_len == 5 && hc[0] == 207 && hc[2] == 112 && hc[3] == 56 && hc[4] == 0 && (hc[1] & 31) >= 9)
+    // ... and its swap wave addresses the table with 32-bit buffer offsets (window * 2048, a drop sentinel at 2 GiB): a table
+    // of more than 2 GiB (cm 30 and up) stays with the family chosen above
+    if (m.hcomp_len == 5 && hc[0] == 207 && hc[2] == 112 && hc[3] == 56 && hc[4] == 0 && (hc[1] & 31) >= 9 &&
+        m.comp[0].cm_bytes <= (1ull << 31))
       m.kind = ZH_FAM_CM1 | ZH_HK_SHIFT << 8 | (uint32_t)(hc[1] & 31) << 16;
   }
   return ZPAQHIP_OK;

@@ -29,6 +29,7 @@ struct ScanOut {
 // streaming forms).  The default never stops early.
 struct ScanLimit {
   size_t min_blocks = SIZE_MAX, min_bytes = 0, max_blocks = SIZE_MAX;
+  size_t min_blocks_other = 0;            // != 0: the minimum for a batch that holds any block with other than one component
 };
 int scan_stream(const uint8_t *in, size_t n, ScanOut &out, zpaqhip_err *err, const ScanLimit &lim = ScanLimit());
 // Parses a stream-form header (hsize[2] hh hm ph pm n COMP 0 HCOMP 0) into a

@@ -33,7 +33,6 @@ using namespace zhdev;
 
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 
-#define C2_TOUCH 0
 #define C2_FINDB 1
 #include "zh_c2_common.h"
 #include "zh_nb_fast.h"

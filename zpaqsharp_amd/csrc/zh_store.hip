@@ -448,6 +448,7 @@ __device__ __attribute__((noinline)) void lz_window(StoreLds &S, Lz &Z, uint32_t
               "v_add_u32_e32 v252, %[ring], v252\n\t"
               "v_add_u32_e32 v253, %[ring], v253\n\t"
               "v_cndmask_b32_e32 v252, %[snk], v252, vcc\n\t"
+              "s_waitcnt lgkmcnt(0)\n\t"                /* v250 is the ds_read_u8 of the code before: LDS returns are not interlocked with VGPR reads */
               "ds_write_b8 v251, v250\n\t"              /* the code before */
               "v_cndmask_b32_e32 v251, %[snk], v253, vcc\n\t"
               "ds_read_u8 v250, v252\n\t"
@@ -480,6 +481,7 @@ __device__ __attribute__((noinline)) void lz_window(StoreLds &S, Lz &Z, uint32_t
               "s_mov_b32 s93, 10\n\t"
               "s_branch .Lz2_got_%=\n"
               ".Lz2_out_%=:\n\t"
+              "s_waitcnt lgkmcnt(0)\n\t"                /* (the read whose byte is written below) */
               "ds_write_b8 v251, v250\n\t"              /* nothing stays pending outside */
               "s_waitcnt lgkmcnt(0)\n\t"
               : [k] "+s"(k), [nb] "+s"(nb), [wp] "+s"(wp), [mb] "+s"(mbits), [ln] "+s"(len), [took] "+s"(took)

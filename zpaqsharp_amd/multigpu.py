@@ -12,7 +12,7 @@ KiB-scale traffic:
 
 Who decodes what is either STATIC — longest-processing-time-first over the estimated block
 costs (zpaqhip_block_costs: plaintext bytes x cycles per byte of the block's kernel) — or
-DYNAMIC: the cost-ordered blocks are dealt into chunks of `queue_blocks` (256: one block per CU of
+DYNAMIC: the cost-ordered blocks are dealt into chunks of `queue_blocks` (default_queue_blocks: 256, one block per CU of
 the GPU that takes the chunk), chunk k = every K-th block of that order, and every rank pulls the
 next chunk from one shared counter whenever it has finished one (`WorkQueue`; the counter is an
 atomic add on the job's rendezvous store, a few bytes per pull), so a GPU that is faster, or
@@ -43,6 +43,15 @@ def lpt_assign(weights: Sequence[int], world: int) -> List[List[int]]:
         shards[r].append(i)
         load[r] += int(weights[i])
     return shards
+
+
+def default_queue_blocks(n_blocks: int, world: int, all_single_cm: bool = False) -> int:
+    """Blocks per pull when the caller does not say: a chunk that fills a GPU (256: one block per CU; 512 where every block is a
+    single-CM one, which run two per CU) — but never so large that a rank gets fewer than four pulls: 2 048 blocks on 8 ranks
+    in chunks of 256 would be one chunk per rank, and the queue could rebalance nothing."""
+    full = 512 if all_single_cm else 256
+    per4 = (n_blocks + 4 * max(1, world) - 1) // (4 * max(1, world))
+    return max(1, min(full, per4))
 
 
 def queue_chunks(costs: Sequence[int], queue_blocks: int = 256) -> List[List[int]]:
@@ -312,7 +321,7 @@ class ShardedJob:
             self._job_id = int(broadcast_table(jid, self.dist, 0, self.coll_dev)[0])
         return f"zpaqhip/queue/{self._job_id}/{self._passes}"
 
-    def decode_dynamic(self, d_out, out_off, out_cap, counter=None, queue_blocks: int = 256, decode_fn=None, **opt) -> np.ndarray:
+    def decode_dynamic(self, d_out, out_off, out_cap, counter=None, queue_blocks: int = 0, decode_fn=None, **opt) -> np.ndarray:
         """One pass over the whole stream with the ranks pulling chunks from the shared queue (module docstring).
         `out_off` / `out_cap` are indexed by GLOBAL block id and must be the same on every rank — a block lands at
         the same offset of whichever rank's `d_out` decodes it.  Returns the [n_blocks, 3] table {status, out_len,
@@ -328,8 +337,12 @@ class ShardedJob:
             else:
                 own_key = self._queue_key()
                 counter = StoreCounter(self._queue_store(), own_key)
-        q = WorkQueue(self.costs, counter, queue_blocks)
         n = self.sc.n_blocks
+        if not queue_blocks:                                  # 0: default_queue_blocks (>= 4 pulls per rank)
+            world = self.dist.get_world_size() if self.dist is not None else 1
+            queue_blocks = default_queue_blocks(n, world, all(int(b.n_comp) == 1 for b in self.sc.blocks))
+        self.queue_blocks = queue_blocks
+        q = WorkQueue(self.costs, counter, queue_blocks)
         mine = np.full((n, 3), -1, np.int64)
         self.pulled, self.kernel_ms = [], 0.0
         while True:
