@@ -56,12 +56,13 @@ CLOCK_GHZ = 2.4                 # max shader clock (same guide)
 KERNEL_SOURCES = {
     "l1": ("zh_cm.hip", "zh_cm_fast.h", "zh_core.h", "zh_dev.h", "zh_model.h"),
     "chain2": ("zh_chain2.hip", "zh_c2_common.h", "zh_zpaql_native.h", "zh_core.h", "zh_dev.h", "zh_model.h"),
+    "nibble": ("zh_nibble.hip", "zh_nb_fast.h", "zh_nb_fast_mid.h", "zh_c2_common.h", "zh_zpaql_native.h", "zh_core.h", "zh_dev.h", "zh_model.h"),
 }
 
 
 def source_hash(model=None):
     """Identifies the kernel a PMC summary or an instruction count was taken with: SHA-1 over the device sources of the
-    decode kernel of `model` (l1 -> zh_cm.hip and its headers; min / mid / max[+e8e9] -> zh_chain2.hip and its headers);
+    decode kernel of `model` (l1 -> zh_cm.hip and its headers; min / mid -> zh_nibble.hip, max[+e8e9] -> zh_chain2.hip and theirs);
     model None: every device source of libzpaqhip (zpaqsharp_amd/csrc/*.hip, *.h)."""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "zpaqsharp_amd", "csrc")
@@ -69,7 +70,7 @@ def source_hash(model=None):
         files = sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip")))
     else:
         base = model.replace("_", "+").split("+")[0]
-        files = [os.path.join(d, f) for f in sorted(KERNEL_SOURCES["l1" if base == "l1" else "chain2"])]
+        files = [os.path.join(d, f) for f in sorted(KERNEL_SOURCES["l1" if base == "l1" else "nibble" if base in ("min", "mid") else "chain2"])]
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
@@ -162,7 +163,7 @@ def roofline(base_model, kms, plain_bytes, rho, nb, bs, model_tag):
 # committed as profiles/<round>/instr_<kernel>.json with the hash of the sources they were counted on.  A count taken on
 # other sources than the ones this run uses is refused, like a stale PMC summary.  A lone wavefront issues at most one
 # instruction per 4 cycles (tools/ubench/salu_bench), which is the ceiling the measured cycles per byte are set against.
-INSTR_KERNEL = {"l1": "zh_decode_cm", "min": "zh_decode_c2_min", "mid": "zh_decode_c2_mid", "max": "zh_decode_c2_max"}
+INSTR_KERNEL = {"l1": "zh_decode_cm", "min": "nb_fast_min", "mid": "nb_fast_mid", "max": "zh_decode_c2_max"}
 ISSUE_CYCLES_PER_INSTR = 4
 
 

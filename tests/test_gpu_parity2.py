@@ -584,3 +584,70 @@ def test_kernel_families_side_by_side_and_one_after_the_other_agree(ctx):
         assert ctx.decompress(s2, verify_sha1=True).tobytes() == want2
     finally:
         del os.environ["ZPAQHIP_SERIAL_FAMILIES"]
+
+
+def test_nibble_kernels_and_their_assembly_loops_match_the_oracle(ctx):
+    """zh_nibble.hip (round 5): the built-in min and mid models decoded a nibble at a time, the byte loop in hand-laid assembly
+    (zh_nb_fast.h / zh_nb_fast_mid.h) with the C++ form of the same loop for every byte the assembly does not take.  Inputs
+    that walk every way out of and back into the assembly loop — blocks shorter than its 40-byte look-ahead, empty and
+    one-byte segments, several segments per block, chunk refills on incompressible data, 256-byte output flushes at odd block
+    offsets — and the ones that stress its forwarding and patch paths: runs (every level trains the entry the next one
+    reads), two-symbol data (hash rows of one bucket written back and probed again at once), long repeats (MATCH verify
+    beyond 64 bytes).  Both kernels (opts.kernel 0: nibble, 9: bit at a time) against the oracle and the plaintext."""
+    rng = np.random.default_rng(2025)
+    cases = {
+        "text": util.text(200000, seed=21),
+        "tiny": b"xyz",
+        "zeros": bytes(70000),
+        "runs": np.repeat(rng.integers(0, 256, 3000, dtype=np.uint8), 37).tobytes(),
+        "two": rng.integers(0, 2, 90000, dtype=np.uint8).tobytes(),
+        "random": rng.integers(0, 256, 120000, dtype=np.uint8).tobytes(),
+        "repeat": (util.text(700, seed=5) * 200)[:130000],
+        "period3": (b"abc" * 40000)[:100001],
+    }
+    for model in ("min", "mid"):
+        m = models.get(model)
+        for name, data in cases.items():
+            s = util.block(model, data)
+            want = oracle.decompress(s, cap=len(data) + 16) if len(data) <= 130000 else data
+            assert want == data
+            for kernel in (0, 9):
+                got = ctx.decompress(s, verify_sha1=True, kernel=kernel, out_cap=len(data) + 16).tobytes()
+                assert got == data, (model, name, kernel)
+        # several segments, some empty, in one block; then many blocks at odd output offsets in one launch
+        parts = [cases["text"][:33333], b"", b"q", cases["runs"][:20001], cases["random"][:7]]
+        c = oracle.Compressor(400000)
+        c.write_tag(); c.start_block(m.header)
+        for i, part in enumerate(parts):
+            c.start_segment(b"f%d" % i, str(len(part)).encode())
+            if i == 0:
+                c.post_process(m.pcomp)
+            c.compress(part)
+            c.end_segment(oracle.sha1(part))
+        c.end_block()
+        ms = c.getvalue(); c.close()
+        assert ctx.decompress(ms, verify_sha1=True).tobytes() == b"".join(parts), model
+        sizes = [1, 39, 40, 41, 255, 256, 257, 1000, 4097, 30011]
+        blocks = [util.text(n, seed=100 + n) for n in sizes] * 3
+        st = b"".join(util.block(model, d) for d in blocks)
+        assert ctx.decompress(st, verify_sha1=True).tobytes() == b"".join(blocks), model
+        # damage: whatever the oracle makes of a flipped bit or a cut stream (garbage that ends in an error, or an error at once),
+        # the assembly loop's range tests and its hand-over to the general form report the same
+        good = util.block(model, cases["text"][:60000])
+        g = z.scan(good).segments[0]
+        for trial in range(8):
+            dmg = bytearray(good)
+            pos = int(g.data_off + rng.integers(4, g.data_len - 8))
+            dmg[pos] ^= 1 << int(rng.integers(0, 8))
+            if bytes(dmg[pos - 3:pos + 4]).count(0) >= 4:
+                continue
+            for stream in (bytes(dmg), good[:g.data_off + g.data_len // 2] + b"\0\0\0\0" + bytes([254, 255])):
+                try:
+                    want = ("ok", oracle.decompress(stream, cap=1 << 20))
+                except oracle.OracleError as e:
+                    want = ("err", str(e))
+                try:
+                    got = ("ok", ctx.decompress(stream).tobytes())
+                except z.ZpaqError as e:
+                    got = ("err", str(e))
+                assert got == want, (model, trial, pos)

@@ -29,7 +29,10 @@ sys.path.insert(0, ROOT)
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 # kernel symbol, decoder steps with a multiply inside the byte loop (zh_cm_fast.h decodes the EOS flag, p = 0, with a compare)
 # ... and the bytes one pass of the loop decodes (zh_cm_fast.h lays its body out twice)
-KERNELS = {"l1": ("zh_decode_cm", 16, 2), "min": ("zh_decode_c2_min", 9, 1), "mid": ("zh_decode_c2_mid", 9, 1), "max": ("zh_decode_c2_max", 9, 1)}
+# (min / mid: the assembly loop of nb_fast<model> in zh_nibble.hip — a device function, found by its mangled name; its EOS flag is
+# a compare like zh_cm_fast.h's: 8 multiplies per byte)
+KERNELS = {"l1": ("zh_decode_cm", 16, 2, None), "min": ("nb_fast_min", 8, 1, "nb_fastINS_5C2MinELb0E"), "mid": ("nb_fast_mid", 8, 1, "nb_fastINS_5C2MidELb0E"),
+           "max": ("zh_decode_c2_max", 9, 1, None)}
 
 
 def disassemble(lib):
@@ -99,8 +102,8 @@ def main():
     funcs = disassemble(a.lib)
     if a.out:
         os.makedirs(a.out, exist_ok=True)
-    for tag, (sym, nsteps, nbytes) in KERNELS.items():
-        ins = funcs.get(sym)
+    for tag, (sym, nsteps, nbytes, mangled) in KERNELS.items():
+        ins = funcs.get(sym) if not mangled else next((v for k, v in funcs.items() if mangled in k), None)
         if not ins:
             print(f"{sym}: not in the library")
             continue
