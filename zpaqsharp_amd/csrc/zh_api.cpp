@@ -1281,7 +1281,7 @@ int zpaqhip_decompress_multi_stats(const int *devices, size_t n_dev, const uint8
     bool all_cm1 = true;
     for (size_t b = 0; b < nb; ++b) all_cm1 = all_cm1 && so.blocks[b].n_comp == 1;
     const size_t full = all_cm1 ? 512 : 256, per4 = (nb + 4 * n_dev - 1) / (4 * n_dev);
-    chunk_blocks = std::max<size_t>(1, std::min(full, per4));
+    chunk_blocks = n_dev <= 1 ? full : std::max<size_t>(1, std::min(full, per4));     // (one taker: nothing to balance)
   }
   const size_t K = (nb + chunk_blocks - 1) / chunk_blocks;
   std::atomic<size_t> next_chunk{0};

@@ -50,7 +50,9 @@ def default_queue_blocks(n_blocks: int, world: int, all_single_cm: bool = False)
     single-CM one, which run two per CU) — but never so large that a rank gets fewer than four pulls: 2 048 blocks on 8 ranks
     in chunks of 256 would be one chunk per rank, and the queue could rebalance nothing."""
     full = 512 if all_single_cm else 256
-    per4 = (n_blocks + 4 * max(1, world) - 1) // (4 * max(1, world))
+    if world <= 1:
+        return full                                       # one taker: nothing to balance
+    per4 = (n_blocks + 4 * world - 1) // (4 * world)
     return max(1, min(full, per4))
 
 
