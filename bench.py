@@ -203,9 +203,18 @@ def method_streams(z, synth, ctx, kib=4096, blocks=256, threads=None):
     from tools import methods
     bs = kib << 10
     out = []
+    # ... and (round 5) the MODELLED method strings real archives carry (LibZPAQ.makeConfig, LibZPAQ.cs:835-1041): their models are
+    # not the three built-in headers, so they run on the lane-per-component kernel of round 1 (zh_chain.hip) with their
+    # post-processor on one lane — 256 blocks of 64 KiB here: at 3-16 MB/s the default run must stay within minutes
     for mt, what in (("x2,1,4,0,3,22", "lazy2: bit-packed LZ77, no model"), ("x2,2,12,0,7,22", "lzpre: byte-aligned LZ77, no model"),
-                     ("x3,3", "bwtrle: BWT, no model")):
+                     ("x3,3", "bwtrle: BWT, no model"),
+                     ("x0,2,12,0,7,16,1c0,0,511i2", "method 2: lzpre + icm/isse over the parse state"), ("x0,3ci1", "method 3: BWT + icm/isse"),
+                     ("x0,4ci1,1,1,1,2am", "method 4: E8E9 + icm/isse chain + match + mix"),
+                     ("x0,0c0,0,255w1i1c256ci1,1,1,1,1,1,2ac0,2,0,255i1c0,3,0,0,255i1c0,4,0,0,0,255i1mm16ts19t0", "method 5's recipe")):
+        progress(f"method stream {mt[:24]}")
         model, margs = methods.model_of(mt)
+        modelled = model.n > 0
+        bs = (64 << 10) if modelled else (kib << 10)
         s, _ = synth.method_stream(model, margs, "T", blocks, bs, threads=threads)
         got = ctx.decompress(s, out_cap=bs * blocks, verify_sha1=True)          # warm-up (arena allocation) + check
         ok = got.size == bs * blocks and all(np.array_equal(got[b * bs:(b + 1) * bs], synth.plain("T", b, bs)) for b in range(blocks))
@@ -214,7 +223,8 @@ def method_streams(z, synth, ctx, kib=4096, blocks=256, threads=None):
         ctx.decompress(s, out_cap=bs * blocks)
         dt = time.time() - t0
         kms = float(ctx.stats().kernel_ms)
-        out.append({"method": mt, "what": what, "workload": f"{blocks} x {kib} KiB distinct blocks, text-like plaintext, coded {s.size / 1e6:.0f} MB",
+        out.append({"method": mt[:24], "what": what, "kernel": int(ctx.stats().kernel_kind), "block_KiB": bs >> 10,
+                    "workload": f"{blocks} x {bs >> 10} KiB distinct blocks, text-like plaintext, coded {s.size / 1e6:.0f} MB",
                     "value": (bs * blocks / dt / 1e6) if ok else 0.0, "unit": "MB/s (host to host)",
                     "kernel_ms": kms, "kernel_MBps": bs * blocks / (kms * 1e-3) / 1e6 if kms else None, "bit_exact": bool(ok)})
     return out
@@ -333,6 +343,14 @@ def sweep_counts(share):
     return sorted({c for c in (8, 16, 32, 64, 128, top) if c <= top})
 
 
+_T0 = time.time()
+
+
+def progress(msg):
+    """one line on stderr per stage (a run that says nothing for minutes looks hung to whoever watches it)"""
+    print(f"[bench {time.time() - _T0:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 def _r(x, n=2):
     return round(x, n) if isinstance(x, float) else x
 
@@ -372,8 +390,8 @@ def compact_line(line):
         sh = line.get("cpu_share", {})
         out["cpu_share"] = [sh.get("host_logical_cores"), sh.get("affinity_cores"), sh.get("cgroup_cpu_quota_cores")]
     if "method_streams" in line:
-        out["method_streams"] = [{"method": m["method"], "kernel": m.get("kernel"), "value": _r(m["value"], 1), "kernel_MBps": _r(m["kernel_MBps"], 1),
-                                  "bit_exact": m["bit_exact"]} for m in line["method_streams"]]
+        out["method_streams"] = [{"method": m["method"], "kernel": m.get("kernel"), "KiB": m.get("block_KiB"), "value": _r(m["value"], 1),
+                                  "kernel_MBps": _r(m["kernel_MBps"], 1), "bit_exact": m["bit_exact"]} for m in line["method_streams"]]
     if "other_configs" in line:                                  # last: one record per BASELINE-shaped configuration
         oc = []
         for r in line["other_configs"]:
@@ -464,8 +482,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    progress(f"stream written ({gen_s:.1f} s), job planned; warm-up")
     for _ in range(args.warmup):
         step()
+    progress("timed steps")
     kernel_ms = []
     barrier()
     t0 = time.perf_counter()
@@ -524,6 +544,7 @@ def main():
     cpu = None
     extras = {}
     block_start = [int(b.tag_off) for b in job.sc.blocks] + [job.stream_len]
+    progress(f"timed region done: {value:.1f} MB/s; cpu baseline")
     if not args.no_cpu_baseline:
         import oracle
         # bounded sample of the SAME stream: first S blocks, one host thread.
@@ -539,6 +560,7 @@ def main():
                          f"oracle/zpaq_oracle.c -O2, 1 thread, host has {ncpu} logical cores"}
         if world == 1 and not args.no_extras:
             # every host core this process may use (SURVEY 8d ii): blocks spread over threads
+            progress("cpu all cores + sweep")
             extras["cpu_all_cores"] = cpu_all_cores(oracle, job.h_stream, block_start, n_glob, bs, max(1, S // 8), max(1, min(usable_cores, 64)))
             # ... and the sweep behind "it does not scale further": one block per thread, 8 threads up to every core the
             # process may use (distinct blocks of the same stream)
@@ -549,6 +571,7 @@ def main():
 
     if world == 1 and not args.no_extras:
         # host buffer -> host buffer through zpaqhip_decompress (scan + H2D + kernel + D2H), pinned memory
+        progress("host to host")
         h_in = torch.from_numpy(job.h_stream).pin_memory()
         h_out = torch.empty(total_plain, dtype=torch.uint8).pin_memory()
         ctx.decompress_into(h_in.numpy(), h_out.numpy())                     # warm-up (allocations)
@@ -571,22 +594,25 @@ def main():
                     ("min", "T", ebs, nd, "BASELINE configs[1], L1' (built-in min: icm + isse, SURVEY 8d config 2)"),
                     ("l1", "X", small, 256, "BASELINE configs[1] on generator X (x86-like: ~20 % window misses)"),
                     ("l1", "R", small, 256, "BASELINE configs[1] on generator R (uniform random: ~75 % window misses)"))
-            for mname, mkind, ebs, nd, cfg in runs:
-                v, k, r, okx, sx, xs, xsc = resident_run(z, synth, torch, ctx, dev, mname, mkind, 256, ebs, gen_threads, args.cache_dir, nd)
+            runs = tuple((a, b, c, d, e, 256) for a, b, c, d, e in runs) + (
+                    ("l1", "T", 1 << 20, 256, "configs[1] > 256 blocks (two per CU)", 1024), ("mid", "T", 1 << 20, 64, "configs[2] > 256 blocks (one per CU)", 1024))
+            for mname, mkind, ebs, nd, cfg, xnb in runs:
+                progress(f"other config: {xnb} x {ebs >> 10} KiB {mname} {mkind}")
+                v, k, r, okx, sx, xs, xsc = resident_run(z, synth, torch, ctx, dev, mname, mkind, xnb, ebs, gen_threads, args.cache_dir, nd)
                 rec = {
                     "config": cfg,
-                    "workload": f"256 x {ebs >> 10} KiB blocks, model {mname}, plaintext {mkind}"
-                                + (f" ({nd} distinct blocks, repeated {256 // nd} x: each block decodes independently in its own arena slot)" if nd < 256 else ""),
+                    "workload": f"{xnb} x {ebs >> 10} KiB blocks, model {mname}, plaintext {mkind}"
+                                + (f" ({nd} distinct blocks, repeated {xnb // nd} x: each block decodes independently in its own arena slot)" if nd < xnb else ""),
                     "value": v if okx else 0.0, "unit": "MB/s", "bit_exact": bool(okx), "kernel_kind": int(sx.kernel_kind),
-                    "roofline": roofline(mname.split("+")[0], k, 256 * ebs, r, 256, ebs, mname)}
-                if not args.no_cpu_baseline:
+                    "roofline": roofline(mname.split("+")[0], k, xnb * ebs, r, xnb, ebs, mname)}
+                if not args.no_cpu_baseline and xnb == 256:
                     xstart = [int(b.tag_off) for b in xsc.blocks] + [int(xs.size)]
                     t0 = time.perf_counter()
                     out = oracle.decompress(xs[:xstart[1]].tobytes(), cap=ebs + 16)
                     dt = time.perf_counter() - t0
                     rec["cpu_baseline"] = {"value": len(out) / dt / 1e6, "unit": "MB/s", "cores": 1, "kind": "port",
                                            "sample": f"first block ({ebs >> 20} MiB plaintext) of the same stream, oracle/zpaq_oracle.c -O2, 1 thread"}
-                    rec["cpu_all_cores"] = cpu_all_cores(oracle, xs, xstart, 256, ebs, 1, max(1, min(usable_cores, 32)))
+                    rec["cpu_all_cores"] = cpu_all_cores(oracle, xs, xstart, xnb, ebs, 1, max(1, min(usable_cores, 32)))
                     if mname == "mid":                           # the sweep for the deep chain: 1 MiB of a block per thread would not
                         mid_small, _ = make_stream(synth, models.get("mid"), "mid", "T", 8, 1 << 20, 0, gen_threads, args.cache_dir)   # end a run: 8 distinct 1 MiB blocks
                         msc = z.scan(mid_small)
@@ -595,7 +621,9 @@ def main():
                                                                sweep_counts(cpu_share()))
                 del xs
                 extras.setdefault("other_configs", []).append(rec)
+            progress("method streams")
             extras["method_streams"] = method_streams(z, synth, ctx, threads=gen_threads)
+            progress("done")
 
     line = {
         "metric": "decompress MB/s (bit-exact) on 1 GiB multi-block stream",

@@ -8,5 +8,5 @@ for m in "$@"; do
   python3 -c "
 import json
 d=json.load(open('gpurun_out/lines/${t}_256x4MiB_bench.json')); r=d['roofline']
-print('$m', round(d['value'],2), d['bit_exact'], 'kernel_ms', round(r['kernel_ms'],1), 'traffic', r['traffic'], 'instr', r['issue']['decoder_wave_instr_per_plain_byte'])"
+print('$m', round(d['value'],2), d['bit_exact'], 'kernel_ms', round(r['kernel_ms'],1), 'traffic', r['traffic'], 'instr', r.get('instr_per_byte'), 'cycles/byte', r.get('cycles_per_byte'))"
 done
