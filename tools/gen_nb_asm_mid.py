@@ -61,6 +61,7 @@ S.y1 = "s59"
 S.mw = "s[46:47]"       # a mask temporary
 
 PROF = False
+PROF_FINE = bool(int(os.environ.get('NB_PROF_FINE', '0')))     # diagnostic: three more stamps inside every level (9: chain done, 10: squash back, 11: decoded)
 
 
 def stamp(i):
@@ -164,6 +165,8 @@ def nibble(n, mr):
             src = R.p
             if t < 4:
                 o("\n".join(gaps[t]))
+        if PROF_FINE:
+            stamp(9)
         # ---- the mixer (Predictor.cs:302-316): dot product over the group's eight lanes, every lane ends with the sum
         fill2 = pmv_part1(d + 1)[1:2] if d < 4 else [f"v_lshrrev_b32_e32 {R.u[1]}, 7, {T[6]}"]
         fill3 = (pmv_part1(d + 1)[2:] + ["s_nop 0"]) if d < 4 else [f"v_and_b32_e32 {R.u[0]}, 0x1fffe, {R.u[0]}", f"v_and_b32_e32 {R.u[1]}, 0x1fffe, {R.u[1]}"]
@@ -190,6 +193,8 @@ def nibble(n, mr):
       ds_read_i16 {T[2]}, {R.u[0]}
       ds_read_i16 {T[3]}, {R.u[1]}
       s_waitcnt lgkmcnt(2)""")
+        if PROF_FINE:
+            stamp(10)
         o(f"""
       v_lshl_or_b32 {R.psv}, {R.sqm}, 17, {R.k_c10000}""")
         if d < 4:
@@ -201,6 +206,8 @@ def nibble(n, mr):
       v_add_u32_e32 {T[1]}, 16, {R.e}
       v_mul_i32_i24_e32 {R.em}, {R.em}, {R.k_rate}"""
             dec_step(tag, shadow)
+            if PROF_FINE:
+                stamp(11)
             o(f"""
       v_ashrrev_i32_e32 {T[0]}, 13, {T[0]}
       v_ashrrev_i32_e32 {T[1]}, 5, {T[1]}
