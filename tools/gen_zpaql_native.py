@@ -208,6 +208,11 @@ def render_native() -> str:
     for name, header in progs:
         items.append((name, zpaql.parse_header(header)[5]))
     items.append(("pcomp_e8e9", models.get("max+e8e9").pcomp))
+    # HCOMP of the reference's level-4 and BWT level-3 method strings (LibZPAQ.makeConfig for `ci1,1,1,1,2am` and `ci1`:
+    # the text does not depend on the block-size argument).  zh_nibble.hip runs them on its helper wave.
+    from tools import methods
+    items.append(("hcomp_m4", zpaql.parse_header(methods.model_of("x0,0ci1,1,1,1,2am")[0].header)[5]))
+    items.append(("hcomp_m3", zpaql.parse_header(methods.model_of("x0,3ci1")[0].header)[5]))
     lines = ["// zh_zpaql_native.h — GENERATED by tools/gen_zpaql_native.py from zpaqsharp_amd/models.py; do not edit.",
              "// Native (ahead-of-time translated) forms of the ZPAQL programs this repo knows; see the generator.",
              "#pragma once", "#include <stdint.h>", "#include <string.h>", "", '#include "zh_core.h"', "",

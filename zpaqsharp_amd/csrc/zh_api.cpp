@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "zh_host.h"
+#include "zh_zpaql_native.h"
 
 extern "C" hipError_t zh_launch_generic(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
 extern "C" hipError_t zh_launch_cm(const ZhLaunch *L, uint32_t grid, hipStream_t stream);
@@ -325,6 +326,12 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     if (f == ZH_FAM_STORE && (opts.reserved[0] == kPpOnlyMagic)) f = ZH_FAM_GENERIC;
     if (opts.kernel == 3 && f == ZH_FAM_CM1) f = ZH_FAM_CHAIN;   // force the lane-per-component kernel
     if (opts.kernel == 4 && f > ZH_FAM_CHAIN) f = ZH_FAM_CHAIN;  // lane-per-component kernel without model specialisation
+    // the method models of min's / mid's shape (zh_framing.cpp) are known to zh_nibble.hip only: the older kernels of these
+    // families carry the built-in HCOMP programs
+    if ((opts.kernel == 9 || opts.kernel == 7 || opts.kernel == 8 || opts.kernel == 5) && f > ZH_FAM_CHAIN && f < ZH_FAM_STORE) {
+      const uint32_t hk = (models[bd[k].model].kind >> 8) & 255u;
+      if (hk == ZH_NATIVE_HCOMP_M4 || hk == ZH_NATIVE_HCOMP_M3) f = ZH_FAM_CHAIN;
+    }
     return f;
   };
   std::vector<std::vector<uint32_t>> groups(ZH_NFAM);

@@ -435,14 +435,29 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
   if ((m.kind & 255u) == ZH_FAM_CHAIN) {
     uint32_t spec = zh_spec_lookup(hdr, len);                            // {0 none, 1 min, 2 mid, 3 max}
     const uint32_t native = zh_native_lookup(hdr + cp, m.hcomp_len);     // native HCOMP id or 0
+    // The models LibZPAQ.makeConfig writes for the method strings `ci1,1,1,1,2am` (level 4) and `ci1` (BWT, level 3) have
+    // the component lists of mid and min with other sizes (they follow the block-size argument) and their own HCOMP.
+    // zh_nibble.hip takes table sizes from the model at run time and lets its helper wave run the program the model names
+    // (bits 8-15 of kind), so these models join mid's / min's family.  Its 32-bit buffer offsets want the arena below 2 GiB.
+    bool method_model = false;
+    if (spec == 0 && native == ZH_NATIVE_HCOMP_M4 && m.hh == 9 && m.hm == 16 && m.n == 8 && m.arena_bytes < (1ull << 31)) {
+      bool ok4 = m.comp[0].type == ZH_ICM && m.comp[6].type == ZH_MATCH && m.comp[7].type == ZH_MIX;
+      for (uint32_t i = 1; ok4 && i <= 5; ++i) ok4 = m.comp[i].type == ZH_ISSE && m.comp[i].arg[1] == i - 1;
+      const uint8_t *mx = m.comp[7].arg;                                 // mix N 0 7 rate 255 over components 0..6
+      if (ok4 && mx[1] == 0 && mx[2] == 7 && mx[4] == 255 && mx[0] >= 8) { spec = 2; method_model = true; }
+    }
+    if (spec == 0 && native == ZH_NATIVE_HCOMP_M3 && m.hh == 9 && m.hm == 16 && m.n == 2 && m.arena_bytes < (1ull << 31) &&
+        m.comp[0].type == ZH_ICM && m.comp[1].type == ZH_ISSE && m.comp[1].arg[1] == 0) {
+      spec = 1; method_model = true;
+    }
     // zh_chain2.hip's max code relies on what the built-in HCOMP leaves in h[17..21] (zeros, and an even h[20])
     if (spec == 3 && (native != ZH_NATIVE_HCOMP_MAX || m.hh != 5 || m.hm != 9)) spec = 0;
     // ... its min / mid code hands HCOMP to a helper wavefront that runs the translated program of that model for 16
     // candidate bytes at once, with H and M of exactly the built-in sizes
-    if (spec == 1 && (native != ZH_NATIVE_HCOMP_MIN || m.hh != 1 || m.hm != 2)) spec = 0;
-    if (spec == 2 && (native != ZH_NATIVE_HCOMP_MID || m.hh != 3 || m.hm != 3)) spec = 0;
+    if (spec == 1 && !method_model && (native != ZH_NATIVE_HCOMP_MIN || m.hh != 1 || m.hm != 2)) spec = 0;
+    if (spec == 2 && !method_model && (native != ZH_NATIVE_HCOMP_MID || m.hh != 3 || m.hm != 3)) spec = 0;
     // ... and it keeps H in 256 LDS words and M in one or two vector registers (256 / 512 bytes)
-    if (spec && (m.hh > 8 || m.hm > (spec == 3 ? 9u : 8u))) spec = 0;
+    if (spec && !method_model && (m.hh > 8 || m.hm > (spec == 3 ? 9u : 8u))) spec = 0;
     m.kind += spec;
     m.kind |= native << 8;
   }

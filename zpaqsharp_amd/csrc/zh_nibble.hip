@@ -18,8 +18,9 @@
 //
 // What this removes from a bit of zh_chain2.hip (mid: 127 instructions): the both-ways fetch and its selects (25), y's
 // hand-over (5), the dependent LDS walk state -> entry at every bit, and every wait of the vector side for the decoder.
-// The helper wavefront (zh_c2_common.h: HCOMP for the 16 values the byte can still take, and the hash rows / mixer row
-// the next byte starts with) is unchanged.  Results are bit-exact with zh_chain2.hip and the oracle (tests/).
+// The helper wavefront (nb_helper below: HCOMP for the 32 values the byte can still take once three of its bits are known,
+// and the hash rows / mixer row the next byte starts with) is zh_c2_common.h's with twice the candidates.  Results are
+// bit-exact with zh_chain2.hip and the oracle (tests/).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,6 +28,7 @@
 #include "zh_dev.h"
 #include "zh_model.h"
 #include "zh_zpaql_native.h"
+#include "zh_zpaql_pcomp.h"
 
 using namespace zhcore;
 using namespace zhdev;
@@ -42,6 +44,31 @@ using namespace zhdev;
 #endif
 
 namespace {
+
+// ---- the models this file decodes.  Shape 1: ICM + ISSE (min); shape 2: ICM, five ISSE, MATCH, MIX (mid).  Table sizes are
+// run-time values (ZhComp), so the models LibZPAQ.makeConfig writes for the method strings `ci1` (BWT, level 3) and
+// `ci1,1,1,1,2am` (level 4) are the same two shapes with another HCOMP program: zh_framing.cpp gives them the family of
+// min / mid with that program's id in ZhModel.kind, and the helper wave runs the program the block's model names.
+// Those programs (zh_native_hcomp_m3 / _m4) keep the last bytes in a 64 KiB ring M (hm = 16: `c-- *c=a`) and read
+// M[c] / M[c .. c+5] only: the helper wave keeps the ring's last 4 / 8 bytes (index & 3 / & 7, the size of min's / mid's M
+// — a slot is overwritten four / eight bytes after it was written, and both arrays start as zeros).  Their first line
+// stores C into H[(a + 255) & 511], a word no component reads (hh = 9, components read H[0 .. n-1]): the H view below
+// drops stores outside the words it stages.
+template <class SP> struct NbT { static constexpr uint32_t shape = SP::id; };
+template <int NH>
+struct NbSpecH {                                // SpecH (zh_c2_common.h) that ignores words >= NH
+  lds_u32_p base;
+  uint32_t *hs, *wmask;
+  struct Ref {
+    const NbSpecH *h; uint32_t d;
+    __device__ __forceinline__ operator uint32_t() const { return d >= (uint32_t)NH ? 0u : ((*h->wmask >> d) & 1u) ? h->hs[d] : h->base[d]; }
+    __device__ __forceinline__ const Ref &operator=(uint32_t x) const {
+      if (d < (uint32_t)NH) { h->hs[d] = x; *h->wmask |= 1u << d; }
+      return *this;
+    }
+  };
+  __device__ __forceinline__ Ref operator[](uint32_t d) const { return Ref{this, d}; }
+};
 
 // The helper wave starts when THREE bits of a byte are known and prepares the next byte for the 32 values it can still take
 // (zh_chain2.hip: four bits, 16 values).  The nibble-at-a-time decoder gets through a nibble in about the time a hash row takes
@@ -70,6 +97,7 @@ struct alignas(16) NbLds {
   uint32_t seloff[NU][kNbCand];
   uint32_t mb_nib, mb_byte, mb_ready;
   uint32_t mb_cmd, mb_ack, mb_model;
+  alignas(16) uint32_t pimm[64];              // operands of a structurally matched PCOMP (zh_zpaql_pcomp.h)
   uint32_t fxs[96];                           // nb_fast: scalars in and out (kFx*)
   uint32_t fxv[64][64];                       // ... and per-lane words (NbV, the coded chunk, the parked output)
   uint32_t fxk[kNmK_count][64];               // zh_nb_fast*.h: per-lane constants of the assembly loop
@@ -140,6 +168,7 @@ __device__ void nb_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const ZhModel *M = &L.models[uni(c2_ld(&S.mb_model))];
     const uint32_t arena_bytes = uni((uint32_t)M->arena_bytes);
+    const uint32_t hprog = uni((M->kind >> 8) & 255u);      // which translated HCOMP program this block's model carries
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(slot_mem, 0, (int)arena_bytes, 0x00020000);
     // this lane's units: u = grp, grp + 2, ... (rows of unit u for candidate `cand`)
     uint32_t u_hto[RN], u_mask[RN], u_comp[RN], u_sb2[RN];
@@ -179,9 +208,15 @@ __device__ void nb_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
 #pragma unroll
       for (uint32_t d = 0; d < NH; ++d) hs[d] = 0;
       const SpecM sm{(lds_u8_p)lds_off(S.mreg), &wi, &wv, &wn};
-      const SpecH<NH> sh{(lds_u32_p)lds_off(S.hreg), hs, &wmask};
-      if constexpr (SP::id == 1) (void)zh_native_hcomp_min(sa, sb, sc, sd, sf, x, sm, (1u << SP::hm) - 1u, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
-      else (void)zh_native_hcomp_mid(sa, sb, sc, sd, sf, x, sm, (1u << SP::hm) - 1u, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
+      const NbSpecH<NH> sh{(lds_u32_p)lds_off(S.hreg), hs, &wmask};
+      constexpr uint32_t mmask_ = (1u << SP::hm) - 1u;
+      if constexpr (SP::id == 1) {
+        if (hprog == ZH_NATIVE_HCOMP_M3) (void)zh_native_hcomp_m3(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, S.r, (Sink *)nullptr, L.budget);
+        else (void)zh_native_hcomp_min(sa, sb, sc, sd, sf, x, sm, mmask_, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
+      } else {
+        if (hprog == ZH_NATIVE_HCOMP_M4) (void)zh_native_hcomp_m4(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, S.r, (Sink *)nullptr, L.budget);
+        else (void)zh_native_hcomp_mid(sa, sb, sc, sd, sf, x, sm, mmask_, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
+      }
       if (grp == 0) {
 #pragma unroll
         for (uint32_t d = 0; d < NH; ++d) S.hspec[d][cand] = (uint32_t)sh[d];
@@ -264,7 +299,7 @@ __device__ void nb_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
 // ---- per-lane constants: the component this lane stands for and the path its group walks ----------------------------
 template <class SP>
 struct NbK {
-  static constexpr uint32_t NC = SP::id == 1 ? 2u : 8u;          // lanes of a group
+  static constexpr uint32_t NC = NbT<SP>::shape == 1 ? 2u : 8u;          // lanes of a group
   static constexpr uint32_t NG = 8u;                               // groups: the 3-bit prefixes of a nibble's path
   static constexpr uint64_t kII = SP::icm | SP::isse;
   static constexpr uint32_t mx_m4 = SP::mix_m[0] * 4u;
@@ -752,7 +787,44 @@ __device__ __forceinline__ bool nb_boundary(const NbK<SP> &K, NbV &V, LDS &S, in
 //   1  the EOS flag's step is done and something about it is unusual (fxs[kFxJ], kFxBad, kFxRn hold its results)
 //   2  error (fxs[kFxStatus])
 enum : int { kFxLow = 0, kFxHigh, kFxCurr, kFxK, kFxAvail, kFxBseq, kFxHelper, kFxWhy, kFxJ, kFxBad, kFxRn, kFxStatus, kFxModel, kFxWord, kFxRoom,
-             kFxLenLo, kFxLenHi, kFxStoredLo, kFxStoredHi, kFxCapLo, kFxCapHi, kFxBaseLo, kFxBaseHi, kFxProf, kFxN = kFxProf + 36 };
+             kFxLenLo, kFxLenHi, kFxStoredLo, kFxStoredHi, kFxCapLo, kFxCapHi, kFxBaseLo, kFxBaseHi,
+             kFxPmode, kFxPnative, kFxPskel, kFxPa, kFxPb, kFxPc, kFxPd, kFxPf, kFxProf, kFxN = kFxProf + 36 };
+static_assert(kFxN <= 96, "S.fxs");
+
+// ---- PostProcessor.write in state 5 (PostProcessor.cs:80-83) for the bytes nb_fast has decoded: the post-processor only
+// consumes the decoded bytes, in order, so the loop parks them exactly as it parks the output of the PASS state and this
+// function feeds the parked chunk's bytes [from, to) (virtual positions, at most 256) to the block's PCOMP — the translated
+// E8E9 (H, M in LDS), a structurally matched program of zh_zpaql_pcomp.h, or the interpreter.  The machine's registers
+// travel in S.fxs.  A real call: none of this belongs to nb_fast's register allocation.
+template <class LDS>
+__device__ __attribute__((noinline)) int nb_pcomp_drain(const ZhLaunch *Lp_, LDS *Sp_, uint32_t park, uint32_t from_, uint32_t to_) {
+  typedef __attribute__((address_space(3))) LDS *lds_S_p;
+  LDS &S = *(LDS *)(lds_S_p)(uintptr_t)uni((uint32_t)(uintptr_t)Sp_);
+  const ZhLaunch &L = *reinterpret_cast<const ZhLaunch *>(uni64((uint64_t)(uintptr_t)Lp_));
+  const uint32_t from = uni(from_), to = uni(to_);
+  const uint32_t pnative = uni(S.fxs[kFxPnative]), pskel = uni(S.fxs[kFxPskel]);
+  uint32_t pa = uni(S.fxs[kFxPa]), pb = uni(S.fxs[kFxPb]), pc_ = uni(S.fxs[kFxPc]), pd = uni(S.fxs[kFxPd]), pf = uni(S.fxs[kFxPf]);
+  Vm &pz = S.pz;
+  Sink &sink = S.sink;
+  int rc = 0;
+  for (uint32_t p = from; p != to; ++p) {
+    const uint32_t w = rdlane(park, (p >> 2) & 63u);
+    const uint32_t c = (w >> ((p & 3u) * 8u)) & 255u;
+    if (pnative == ZH_NATIVE_PCOMP_E8E9)
+      rc = zh_native_pcomp_e8e9(pa, pb, pc_, pd, pf, c, (lds_u8_p)lds_off(S.pmreg), uni(pz.mmask), (lds_u32_p)lds_off(S.phreg), uni(pz.hmask), S.pr, &sink, L.budget);
+    else if (pskel) {
+      ZhPcRegs r{pa, pb, pc_, pd, pf, 0};
+      r = zh_pcomp_call(pskel, r, c, pz.m, pz.mmask, pz.h, pz.hmask, S.pr, &sink, L.budget, S.pimm);
+      pa = r.a; pb = r.b; pc_ = r.c; pd = r.d; pf = r.f;
+      rc = r.rc;
+    } else rc = vm_run(pz, c, &sink, L.budget);
+    rc = (int)uni((uint32_t)rc);
+    if (rc) break;
+  }
+  if ((threadIdx.x & 63u) == 0) { S.fxs[kFxPa] = pa; S.fxs[kFxPb] = pb; S.fxs[kFxPc] = pc_; S.fxs[kFxPd] = pd; S.fxs[kFxPf] = pf; }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  return rc;
+}
 template <class SP, bool PROF, class LDS>
 __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_) {
   // (arguments of a real call arrive in vector registers: say that they are the same in every lane, or every buffer access
@@ -786,16 +858,17 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
   ob.stored = (uint64_t)uni(S.fxs[kFxStoredLo]) | (uint64_t)uni(S.fxs[kFxStoredHi]) << 32;
   ob.word = uni(S.fxs[kFxWord]); ob.room = uni(S.fxs[kFxRoom]); ob.park = S.fxv[kNbVWords + 1][lane];
   uint32_t bseq = uni(S.fxs[kFxBseq]);
+  const uint32_t pmode = uni(S.fxs[kFxPmode]);          // 1: post-processor program loaded — `ob` is a staging cursor, chunks go to nb_pcomp_drain
   bool helper_ok = true;
   uint32_t why = 0, j = 0, bad = 0, rn = 0, status = 0;
   const uint32_t klim = in.avail >= 40u ? in.avail - 40u : 0u;
   uint32_t vlo = (uint32_t)(uintptr_t)ob.base + (uint32_t)ob.len;     // low bits of the virtual output position
   uint32_t nput = 0, room = ob.room, word = ob.word;
-  if constexpr ((SP::id == 1 || SP::id == 2) && ZH_NB_ASM != 0) {
+  if constexpr (ZH_NB_ASM != 0) {
     // ---- the loop in assembly (zh_nb_fast.h, tools/gen_nb_asm.py): constants and state through LDS
     if (lds_off(S.stretch) == 0 && V.rowvalid) {
       const uint32_t hmask_ = (1u << SP::hh) - 1u;
-      constexpr int kNK = SP::id == 2 ? (int)kNmK_count : (int)kNbK_count;
+      constexpr int kNK = NbT<SP>::shape == 2 ? (int)kNmK_count : (int)kNbK_count;
       uint32_t kc[kNK];
       kc[kNbK_tab] = K.tab; kc[kNbK_slot] = K.wrow; kc[kNbK_wr2] = K.wrow + K.node[2]; kc[kNbK_wr3] = K.wrow + K.node[3]; kc[kNbK_wr4] = K.wrow + K.node[4];
       kc[kNbK_sh2] = K.sh2; kc[kNbK_sh3] = K.sh3; kc[kNbK_sh4] = K.sh4;
@@ -807,7 +880,7 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
       kc[kNbK_hspec] = lds_off(&S.hspec[K.ci & hmask_][0]); kc[kNbK_rowst] = lds_off(&S.rowst[K.un_][0][0]); kc[kNbK_slotoff] = lds_off(&S.slotoff[K.ci]);
       kc[kNbK_koob] = kOob; kc[kNbK_c2047] = 2047u; kc[kNbK_c512k] = (1u << 19) - 1u; kc[kNbK_rnd] = 1u << 12; kc[kNbK_c10000] = 0x10000u;
       kc[kNbK_evo] = (K.canon && K.l_ii) ? K.hto : kOob; kc[kNbK_mb] = lds_off(&S.mb_nib);
-      if constexpr (SP::id == 2) {
+      if constexpr (NbT<SP>::shape == 2) {
         constexpr uint32_t m4 = NbK<SP>::mx_m4;
         kc[kNmK_rslot] = K.l_ii ? lds_off(&S.slot[K.ci]) : lds_off(&S.zrow);
         kc[kNmK_rate] = (uint32_t)K.mx_rate; kc[kNmK_vomix] = K.vo_mix; kc[kNmK_cm0] = (16u + 2u * K.g) * m4;
@@ -824,7 +897,7 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
       S.fxa[kNbS_ob0][lane] = V.oldb.x; S.fxa[kNbS_ob1][lane] = V.oldb.y; S.fxa[kNbS_ob2][lane] = V.oldb.z; S.fxa[kNbS_ob3][lane] = V.oldb.w;
       S.fxa[kNbS_oboff][lane] = V.oldb_valid ? V.oldb_off : 0xFFFFFFFFu;       // (no row written back yet: a place no bucket has)
       S.fxa[kNbS_cur][lane] = in.cur;
-      if constexpr (SP::id == 2) {
+      if constexpr (NbT<SP>::shape == 2) {
         S.fxa[kNmS_m_len][lane] = V.m_len; S.fxa[kNmS_m_ptr][lane] = V.m_ptr; S.fxa[kNmS_m_limit][lane] = V.m_limit; S.fxa[kNmS_m_byte][lane] = V.m_byte;
         S.fxa[kNmS_pm0][lane] = (uint32_t)V.pm0; S.fxa[kNmS_pm1][lane] = (uint32_t)V.pm1; S.fxa[kNmS_cm_pre][lane] = V.cm_pre;
         S.fxa[kNmS_va_pre][lane] = V.va_pre; S.fxa[kNmS_vb_pre][lane] = V.vb_pre; S.fxa[kNmS_mbn_pre][lane] = V.mbn_pre; S.fxa[kNmS_mbc_pre][lane] = V.mbc_pre;
@@ -843,7 +916,7 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
         S.fxa[kNbS_park][lane] = ob.park;
         const uint32_t vlo_s = uni(vlo);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (SP::id == 2) {
+        if constexpr (NbT<SP>::shape == 2) {
           const uint32_t mxb = uni(K.mx_base), mxs = uni(K.mx_size1), pmb = uni(lds_off(S.pm01));
           if constexpr (PROF) {
             ZH_NB_FAST_MID_LOOP_PROF(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb, mxb, mxs, pmb);
@@ -860,7 +933,11 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
         ob.park = S.fxa[kNbS_park][lane];
         if (asm_why != 3) break;
         ob.len += nput; ob.word = word; ob.room = room; vlo += nput; nput = 0;      // the parked 256-byte chunk is complete
-        out_flush(ob, lane);
+        if (pmode) {
+          const int prc = (int)uni((uint32_t)nb_pcomp_drain<LDS>(Lp_, Sp_, ob.park, (uint32_t)ob.stored, (uint32_t)ob.len));
+          ob.stored = ob.len; out_room(ob);
+          if (UNLIKELY(prc != 0)) { asm_why = 4; status = (uint32_t)prc; break; }
+        } else out_flush(ob, lane);
         room = uni(ob.room);
       }
       d.low = uni(lo_); d.high = uni(hi_); d.curr = uni(cu_); in.k = uni(k_);
@@ -868,7 +945,7 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
       V.rowoff = S.fxa[kNbS_rowoff][lane]; V.hv = S.fxa[kNbS_hv][lane];
       V.oldb.x = S.fxa[kNbS_ob0][lane]; V.oldb.y = S.fxa[kNbS_ob1][lane]; V.oldb.z = S.fxa[kNbS_ob2][lane]; V.oldb.w = S.fxa[kNbS_ob3][lane];
       { const uint32_t oo = S.fxa[kNbS_oboff][lane]; V.oldb_valid = oo != 0xFFFFFFFFu; V.oldb_off = oo; }
-      if constexpr (SP::id == 2) {
+      if constexpr (NbT<SP>::shape == 2) {
         V.m_len = S.fxa[kNmS_m_len][lane]; V.m_ptr = S.fxa[kNmS_m_ptr][lane]; V.m_limit = S.fxa[kNmS_m_limit][lane]; V.m_byte = S.fxa[kNmS_m_byte][lane];
         V.pm0 = (int)S.fxa[kNmS_pm0][lane]; V.pm1 = (int)S.fxa[kNmS_pm1][lane]; V.cm_pre = S.fxa[kNmS_cm_pre][lane];
         V.va_pre = S.fxa[kNmS_va_pre][lane]; V.vb_pre = S.fxa[kNmS_vb_pre][lane]; V.mbn_pre = S.fxa[kNmS_mbn_pre][lane]; V.mbc_pre = S.fxa[kNmS_mbc_pre][lane];
@@ -877,6 +954,7 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
         for (int dd = 1; dd <= 4; ++dd) { V.mwl[dd] = (int)S.fxa[kNmS_mwl1 + dd - 1][lane]; V.mrowl[dd] = S.fxa[kNmS_mra1 + dd - 1][lane]; }
       }
       if (asm_why == 2) { why = 2; status = ofail ? (uint32_t)-24 : (uint32_t)ZH_E_CORRUPT; }
+      if (asm_why == 4) why = 2;                           // the post-processor failed: status holds its code
     }
   } else
   for (;;) {
@@ -901,7 +979,11 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
         ob.park = wrlane(word, (v >> 2) & 63u, ob.park);
         if (UNLIKELY((v & 255u) == 255u)) {
           ob.len += nput; ob.word = word; vlo += nput; nput = 0;
-          out_flush(ob, lane);
+          if (pmode) {
+            const int prc = (int)uni((uint32_t)nb_pcomp_drain<LDS>(Lp_, Sp_, ob.park, (uint32_t)ob.stored, (uint32_t)ob.len));
+            ob.stored = ob.len; out_room(ob);
+            if (UNLIKELY(prc != 0)) { why = 2; status = (uint32_t)prc; break; }
+          } else out_flush(ob, lane);
           room = ob.room;
         }
       }
@@ -909,6 +991,13 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
     NB_STAMP(9);
   }
   ob.len += nput; ob.word = word; ob.room = room;
+  if (pmode && ob.len != ob.stored) {                    // the bytes of the unfinished chunk: the general path's next byte goes to the program directly
+    uint32_t park = ob.park;
+    if ((uint32_t)ob.len & 3u) park = wrlane(ob.word, ((uint32_t)ob.len >> 2) & 63u, park);
+    const int prc = (int)uni((uint32_t)nb_pcomp_drain<LDS>(Lp_, Sp_, park, (uint32_t)ob.stored, (uint32_t)ob.len));
+    ob.stored = ob.len;
+    if (prc != 0 && why != 2) { why = 2; status = (uint32_t)prc; }
+  }
   {
     uint32_t *w = reinterpret_cast<uint32_t *>(&V);
 #pragma unroll
@@ -1036,9 +1125,12 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
     pz.h = phb < 31 && (1u << phb) <= (uint32_t)kPHWords ? S.phreg : reinterpret_cast<uint32_t *>(slot_mem + uni64(M->ph_off));
     pz.r = S.pr;
     const bool p_lds = pz.m == S.pmreg && pz.h == S.phreg;
-    uint32_t pnative = 0;
+    uint32_t pnative = 0, pskel = 0;                    // the loaded program is the translated E8E9 / has the structure of one of zh_zpaql_pcomp.h's
     uint32_t pa = 0, pb = 0, pc_ = 0, pd = 0, pf = 0;
     uint8_t *pzbuf = slot_mem + uni64(M->pz_off) + ZH_CODE_PAD;
+    OutBuf sb;                                          // state 5: the cursor nb_fast parks decoded bytes under on their way to the program
+    sb.base = nullptr; sb.cap = ~0ull; sb.len = 0; sb.stored = 0; sb.word = 0; sb.park = 0;
+    out_room(sb);
 
     Dec d;
     d.low = 1; d.high = 0xFFFFFFFFu; d.curr = 0;
@@ -1103,23 +1195,26 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
         uint32_t bad = 0, rn = 0, j = 0, err = 0;
         bool after_eos = false;
         // ---- the common case runs in nb_fast
-        if (LIKELY(pp_state == 1 && helper_ok)) {
+        if (LIKELY((pp_state == 1 || pp_state == 5) && helper_ok)) {
+          OutBuf &fo = pp_state == 5 ? sb : ob;
           if (in.k + 40u > in.avail && in.cbase + in.avail < in.total) in_seek(in, in_pos(in), lane);   // nb_fast wants >= 40 coded bytes in the chunk: re-base it at the cursor
-          if (d.curr != 0 && in.avail >= 40u && in.k + 40u <= in.avail && ob.room != 0) {
+          if (d.curr != 0 && in.avail >= 40u && in.k + 40u <= in.avail && fo.room != 0) {
             {
               const uint32_t *w = reinterpret_cast<const uint32_t *>(&V);
 #pragma unroll
               for (int i = 0; i < kNbVWords; ++i) S.fxv[i][lane] = w[i];
               S.fxv[kNbVWords][lane] = in.cur;
-              S.fxv[kNbVWords + 1][lane] = ob.park;
+              S.fxv[kNbVWords + 1][lane] = fo.park;
             }
             if (lane == 0) {
               S.fxs[kFxLow] = d.low; S.fxs[kFxHigh] = d.high; S.fxs[kFxCurr] = d.curr; S.fxs[kFxK] = in.k; S.fxs[kFxAvail] = in.avail;
-              S.fxs[kFxBseq] = bseq; S.fxs[kFxModel] = model_i; S.fxs[kFxWord] = ob.word; S.fxs[kFxRoom] = ob.room;
-              S.fxs[kFxLenLo] = (uint32_t)ob.len; S.fxs[kFxLenHi] = (uint32_t)(ob.len >> 32);
-              S.fxs[kFxStoredLo] = (uint32_t)ob.stored; S.fxs[kFxStoredHi] = (uint32_t)(ob.stored >> 32);
-              S.fxs[kFxCapLo] = (uint32_t)ob.cap; S.fxs[kFxCapHi] = (uint32_t)(ob.cap >> 32);
-              S.fxs[kFxBaseLo] = (uint32_t)(uintptr_t)ob.base; S.fxs[kFxBaseHi] = (uint32_t)((uintptr_t)ob.base >> 32);
+              S.fxs[kFxBseq] = bseq; S.fxs[kFxModel] = model_i; S.fxs[kFxWord] = fo.word; S.fxs[kFxRoom] = fo.room;
+              S.fxs[kFxLenLo] = (uint32_t)fo.len; S.fxs[kFxLenHi] = (uint32_t)(fo.len >> 32);
+              S.fxs[kFxStoredLo] = (uint32_t)fo.stored; S.fxs[kFxStoredHi] = (uint32_t)(fo.stored >> 32);
+              S.fxs[kFxCapLo] = (uint32_t)fo.cap; S.fxs[kFxCapHi] = (uint32_t)(fo.cap >> 32);
+              S.fxs[kFxBaseLo] = (uint32_t)(uintptr_t)fo.base; S.fxs[kFxBaseHi] = (uint32_t)((uintptr_t)fo.base >> 32);
+              S.fxs[kFxPmode] = pp_state == 5; S.fxs[kFxPnative] = pnative; S.fxs[kFxPskel] = pskel;
+              S.fxs[kFxPa] = pa; S.fxs[kFxPb] = pb; S.fxs[kFxPc] = pc_; S.fxs[kFxPd] = pd; S.fxs[kFxPf] = pf;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             nb_fast<SP, PROF, LDS>(&L, &S);
@@ -1128,13 +1223,14 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
               uint32_t *w = reinterpret_cast<uint32_t *>(&V);
 #pragma unroll
               for (int i = 0; i < kNbVWords; ++i) w[i] = S.fxv[i][lane];
-              ob.park = S.fxv[kNbVWords + 1][lane];
+              fo.park = S.fxv[kNbVWords + 1][lane];
             }
             d.low = uni(S.fxs[kFxLow]); d.high = uni(S.fxs[kFxHigh]); d.curr = uni(S.fxs[kFxCurr]); in.k = uni(S.fxs[kFxK]);
             bseq = uni(S.fxs[kFxBseq]);
-            ob.word = uni(S.fxs[kFxWord]); ob.room = uni(S.fxs[kFxRoom]);
-            ob.len = (uint64_t)uni(S.fxs[kFxLenLo]) | (uint64_t)uni(S.fxs[kFxLenHi]) << 32;
-            ob.stored = (uint64_t)uni(S.fxs[kFxStoredLo]) | (uint64_t)uni(S.fxs[kFxStoredHi]) << 32;
+            fo.word = uni(S.fxs[kFxWord]); fo.room = uni(S.fxs[kFxRoom]);
+            fo.len = (uint64_t)uni(S.fxs[kFxLenLo]) | (uint64_t)uni(S.fxs[kFxLenHi]) << 32;
+            fo.stored = (uint64_t)uni(S.fxs[kFxStoredLo]) | (uint64_t)uni(S.fxs[kFxStoredHi]) << 32;
+            if (pp_state == 5) { pa = uni(S.fxs[kFxPa]); pb = uni(S.fxs[kFxPb]); pc_ = uni(S.fxs[kFxPc]); pd = uni(S.fxs[kFxPd]); pf = uni(S.fxs[kFxPf]); }
             const uint32_t why = uni(S.fxs[kFxWhy]);
             if (PROF) for (int i = 0; i < 16; ++i) P.prof[i] += (uint64_t)S.fxs[kFxProf + 2 * i] | (uint64_t)S.fxs[kFxProf + 2 * i + 1] << 32;
             if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(P.tprev)::"memory"); }
@@ -1175,6 +1271,12 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
           int rc;
           if (pnative == ZH_NATIVE_PCOMP_E8E9)
             rc = zh_native_pcomp_e8e9(pa, pb, pc_, pd, pf, (uint32_t)c, (lds_u8_p)lds_off(S.pmreg), pz.mmask, (lds_u32_p)lds_off(S.phreg), pz.hmask, S.pr, &sink, L.budget);
+          else if (pskel) {
+            ZhPcRegs r{pa, pb, pc_, pd, pf, 0};
+            r = zh_pcomp_call(pskel, r, (uint32_t)c, pz.m, pz.mmask, pz.h, pz.hmask, S.pr, &sink, L.budget, S.pimm);
+            pa = r.a; pb = r.b; pc_ = r.c; pd = r.d; pf = r.f;
+            rc = r.rc;
+          }
           else rc = vm_run(pz, (uint32_t)c, &sink, L.budget);
           rc = (int)uni((uint32_t)rc);
           if (rc) { status = rc; break; }
@@ -1198,6 +1300,9 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
             pz.prog = pzbuf; pz.len = pp_len;
             pz.a = pz.b = pz.c = pz.d = pz.f = 0;
             pnative = p_lds ? uni(zh_native_lookup(pzbuf, pp_len)) : 0;
+            pskel = pnative ? 0u : uni(zh_pcomp_lookup(pzbuf, pp_len));
+            if (lane == 0) zh_pcomp_operands(pskel, pzbuf, S.pimm);
+            nb_wave_sync();
             pp_state = 5;
           }
         }
@@ -1245,7 +1350,7 @@ ZH_NIBBLE_KERNEL(zh_decode_nb_mid, C2Mid, 6, false)
 ZH_NIBBLE_KERNEL(zh_decode_nb_min_prof, C2Min, 2, true)
 ZH_NIBBLE_KERNEL(zh_decode_nb_mid_prof, C2Mid, 6, true)
 
-// spec: 1 min, 2 mid (zh_chain_spec.h ids)
+// spec: 1 min, 2 mid (zh_chain_spec.h ids; zh_framing.cpp also files the method models of their shapes under them)
 extern "C" hipError_t zh_launch_nibble(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof) {
   void (*k)(ZhLaunch) = spec == 1 ? (prof ? zh_decode_nb_min_prof : zh_decode_nb_min) : spec == 2 ? (prof ? zh_decode_nb_mid_prof : zh_decode_nb_mid) : nullptr;
   if (!k) return hipErrorInvalidValue;
