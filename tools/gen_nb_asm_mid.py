@@ -60,6 +60,8 @@ S.w0, S.w1, S.w2 = "s56", "s57", "s58"
 S.y1 = "s59"
 S.mw = "s[46:47]"       # a mask temporary
 
+MIX_M = 7          # mixer inputs: 7 (mid: lane 7 is the MIX, whose context is h[7]) or 8 (the level-4 text model: lane 7 is an ICM, the
+                   # MIX has no lane and its context h[8] is 0)
 PROF = False
 PROF_FINE = bool(int(os.environ.get('NB_PROF_FINE', '0')))     # diagnostic: three more stamps inside every level (9: chain done, 10: squash back, 11: decoded)
 
@@ -317,12 +319,12 @@ def gen():
       s_mov_b32 s69, 0xffffffff
       s_mov_b32 s70, 0xff
       s_mov_b32 s71, 0
-      s_mov_b32 s40, 0x3f3f3f3f
-      s_mov_b32 s41, 0x3f3f3f3f
+      s_mov_b32 s40, {'0x3f3f3f3f' if MIX_M == 7 else '0xbfbfbfbf'}
+      s_mov_b32 s41, {'0x3f3f3f3f' if MIX_M == 7 else '0xbfbfbfbf'}
       s_mov_b32 s42, 0x40404040
       s_mov_b32 s43, 0x40404040
-      s_mov_b32 s44, 0x7f7f7f7f
-      s_mov_b32 s45, 0x7f7f7f7f
+      s_mov_b32 s44, {'0x7f7f7f7f' if MIX_M == 7 else '0xffffffff'}
+      s_mov_b32 s45, {'0x7f7f7f7f' if MIX_M == 7 else '0xffffffff'}
       s_mov_b32 {S.c24}, 0x1000000
       s_mov_b32 {S.m2048}, 0xfffff800
       s_mov_b32 {S.m512k}, 0xfff80000
@@ -388,7 +390,7 @@ def gen():
     o(f"""
       v_add_u32_e32 {T[4]}, {R.mx_rb}, {R.k_cm0}
       buffer_load_dword {R.cmw[0]}, {T[4]}, %[rs], 0 offen
-      buffer_load_dword {R.cmw[1]}, {T[4]}, %[rs], 0 offen offset:28""")
+      buffer_load_dword {R.cmw[1]}, {T[4]}, %[rs], 0 offen offset:{4 * MIX_M}""")
     stamp(0)
     nibble(0, R.mrA)
     stamp(2)
@@ -402,7 +404,7 @@ def gen():
       v_mul_i32_i24_e32 {T[0]}, {T[0]}, {R.k_rate}
       s_add_u32 {S.t1}, {S.nv}, 16
       v_ashrrev_i32_e32 {T[0]}, 4, {T[0]}
-      s_mul_i32 {S.u[1]}, {S.t1}, 28
+      s_mul_i32 {S.u[1]}, {S.t1}, {4 * MIX_M}
       v_mad_i32_i24 {T[0]}, {T[0]}, {R.pl1}, {R.k_rnd}
       s_lshl_b32 {S.u[2]}, {S.u[1]}, 1
       v_ashrrev_i32_e32 {T[0]}, 13, {T[0]}
@@ -522,11 +524,11 @@ def gen():
     # the mixer's block of rows for the next byte (Predictor.cs:307: its context is h[7]); the first row's weights come staged —
     # unless the block is the one this byte used: then the helper's copy of row c8 = 1 may predate this byte's training of it
     o(f"""
-      v_readlane_b32 {S.w0}, {R.hv}, 7
+      {'v_readlane_b32 ' + S.w0 + ', ' + R.hv + ', 7' if MIX_M == 7 else 's_mov_b32 ' + S.w0 + ', 0'}
       v_mov_b32_e32 {R.rbold}, {R.mx_rb}
       s_and_b32 {S.w0}, {S.w0}, {S.mxsize1}
       s_andn2_b32 {S.w0}, {S.w0}, 0xff
-      s_mul_i32 {S.w0}, {S.w0}, 28
+      s_mul_i32 {S.w0}, {S.w0}, {4 * MIX_M}
       s_add_u32 {S.w0}, {S.w0}, {S.mxbase}
       v_add_u32_e32 {R.mx_rb}, {S.w0}, {R.k_vomix}
       v_cmp_eq_u32_e32 vcc, {R.mx_rb}, {R.rbold}
@@ -758,9 +760,10 @@ def gen():
       s_waitcnt lgkmcnt(0)""")
 
 
-def emit(name, prof):
-    global PROF
+def emit(name, prof, mix_m=7):
+    global PROF, MIX_M
     PROF = prof
+    MIX_M = mix_m
     G.PROF = False
     del L[:]
     gen()
@@ -780,6 +783,8 @@ def emit(name, prof):
 def main():
     t0, n0 = emit("ZH_NB_FAST_MID_LOOP", False)
     t1, _ = emit("ZH_NB_FAST_MID_LOOP_PROF", True)
+    t2, _ = emit("ZH_NB_FAST_MID8_LOOP", False, 8)
+    t3, _ = emit("ZH_NB_FAST_MID8_LOOP_PROF", True, 8)
     head = f"""// zh_nb_fast_mid.h — GENERATED by tools/gen_nb_asm_mid.py (do not edit: edit the generator and run it).
 // The steady-state byte loop of nb_fast (zh_nibble.hip) for the built-in mid model, hand-laid gfx950 assembly.
 #pragma once
@@ -788,7 +793,7 @@ enum : int {{ {", ".join("kNmK_" + n + (" = 0" if i == 0 else "") for i, n in en
 enum : int {{ {", ".join("kNmS_" + n + (" = 0" if i == 0 else "") for i, n in enumerate(VNAMES))}, kNmS_count }};
 // clang-format off
 """
-    text = head + t0 + t1 + "// clang-format on\n"
+    text = head + t0 + t1 + t2 + t3 + "// clang-format on\n"
     if len(sys.argv) > 1 and sys.argv[1] == "--check":
         cur = open(OUT).read() if os.path.exists(OUT) else ""
         sys.exit(0 if cur == text else 1)

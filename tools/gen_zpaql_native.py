@@ -213,6 +213,7 @@ def render_native() -> str:
     from tools import methods
     items.append(("hcomp_m4", zpaql.parse_header(methods.model_of("x0,0ci1,1,1,1,2am")[0].header)[5]))
     items.append(("hcomp_m3", zpaql.parse_header(methods.model_of("x0,3ci1")[0].header)[5]))
+    items.append(("hcomp_m4w", zpaql.parse_header(methods.model_of("x0,0ci1,1,1,1,2awm")[0].header)[5]))
     lines = ["// zh_zpaql_native.h — GENERATED by tools/gen_zpaql_native.py from zpaqsharp_amd/models.py; do not edit.",
              "// Native (ahead-of-time translated) forms of the ZPAQL programs this repo knows; see the generator.",
              "#pragma once", "#include <stdint.h>", "#include <string.h>", "", '#include "zh_core.h"', "",

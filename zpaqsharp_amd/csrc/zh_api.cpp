@@ -77,8 +77,8 @@ struct zpaqhip_ctx {
   uint32_t mem_share = 1;                 // contexts of this process that share the device (zpaqhip_decompress_multi): divides the memory budgets
   // a launch whose blocks need several kernel families (an archive that mixes models): one stream per family, forked from
   // and joined to the launch stream, each family with its own region of the arena
-  hipStream_t fam_stream[ZH_NFAM] = {};
-  hipEvent_t fam_ev[ZH_NFAM] = {};
+  hipStream_t fam_stream[ZH_NFAM_HOST] = {};
+  hipEvent_t fam_ev[ZH_NFAM_HOST] = {};
   hipEvent_t fork_ev = nullptr;
   std::vector<uint32_t> raw_pp;           // last decode: per segment pp_state | PCOMP length << 8, as the kernels report it
 };
@@ -168,7 +168,7 @@ void zpaqhip_ctx_destroy(zpaqhip_ctx *c) {
   if (c->ev_h1) (void)hipEventDestroy(c->ev_h1);
   if (c->s_in) (void)hipStreamDestroy(c->s_in);
   if (c->s_out) (void)hipStreamDestroy(c->s_out);
-  for (uint32_t g = 0; g < ZH_NFAM; ++g) {
+  for (uint32_t g = 0; g < ZH_NFAM_HOST; ++g) {
     if (c->fam_ev[g]) (void)hipEventDestroy(c->fam_ev[g]);
     if (c->fam_stream[g]) (void)hipStreamDestroy(c->fam_stream[g]);
   }
@@ -332,9 +332,10 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
       const uint32_t hk = (models[bd[k].model].kind >> 8) & 255u;
       if (hk == ZH_NATIVE_HCOMP_M4 || hk == ZH_NATIVE_HCOMP_M3) f = ZH_FAM_CHAIN;
     }
+    if ((opts.kernel == 9 || opts.kernel == 7 || opts.kernel == 8 || opts.kernel == 5 || opts.kernel == 4) && f == ZH_FAM_CHAIN_MID8) f = ZH_FAM_CHAIN;
     return f;
   };
-  std::vector<std::vector<uint32_t>> groups(ZH_NFAM);
+  std::vector<std::vector<uint32_t>> groups(ZH_NFAM_HOST);
   for (size_t k = 0; k < sel.size(); ++k) groups[family(k)].push_back((uint32_t)k);
 
   size_t free_b = 0, total_b = 0;
@@ -346,7 +347,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     // If this launch could not give every block (up to 256) its slot, they are released first and the budget taken again
     // (multi([0,0,0,0]) followed by a max-model decode on a context of one's own saw a quarter of the memory).
     uint64_t wish = 0;
-    for (uint32_t g = 0; g < ZH_NFAM; ++g) {
+    for (uint32_t g = 0; g < ZH_NFAM_HOST; ++g) {
       uint64_t stride = 0;
       for (uint32_t k : groups[g]) stride = std::max<uint64_t>(stride, models[bd[k].model].arena_bytes);
       wish += stride * std::min<uint64_t>(groups[g].size(), opts.max_concurrent ? opts.max_concurrent : 256u);
@@ -363,7 +364,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
   HIPCHK(c->bdesc.reserve(sel.size() * sizeof(ZhBlockDesc)));
   HIPCHK(c->sdesc.reserve(sd.size() * sizeof(ZhSegDesc)));
   HIPCHK(c->results.reserve(n_segs * sizeof(ZhSegResult)));
-  static_assert(32 * ZH_NFAM <= kQueueBytes, "one 32-byte work-queue head per kernel family");
+  static_assert(32 * ZH_NFAM_HOST <= kQueueBytes, "one 32-byte work-queue head per kernel family");
   HIPCHK(c->queue.reserve(kQueueBytes + kDebugBytes));   // [heads | diagnostic cycle sums]: the two never overlap
   HIPCHK(hipMemcpyAsync(c->models.p, models.data(), models.size() * sizeof(ZhModel), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(c->code.p, code.data(), code.size(), hipMemcpyHostToDevice, stream));
@@ -374,12 +375,12 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
   // arena: one region per kernel family when all of them fit at once (the families then run side by side: an archive
   // that mixes models fills the GPU with whatever blocks it has), else one region sized for the most demanding family,
   // used by one family after the other
-  uint32_t slots_of[ZH_NFAM] = {};
-  bool cm_x2[ZH_NFAM] = {};
-  uint64_t stride_of[ZH_NFAM], arena_need = 0, arena_sum = 0, arena_off[ZH_NFAM] = {};
+  uint32_t slots_of[ZH_NFAM_HOST] = {};
+  bool cm_x2[ZH_NFAM_HOST] = {};
+  uint64_t stride_of[ZH_NFAM_HOST], arena_need = 0, arena_sum = 0, arena_off[ZH_NFAM_HOST] = {};
   uint32_t n_fam = 0;
   for (auto &x : stride_of) x = 256;
-  for (uint32_t g = 0; g < ZH_NFAM; ++g) {
+  for (uint32_t g = 0; g < ZH_NFAM_HOST; ++g) {
     if (groups[g].empty()) continue;
     for (uint32_t k : groups[g]) stride_of[g] = std::max<uint64_t>(stride_of[g], models[bd[k].model].arena_bytes);
     uint64_t max_slots = mem_budget / stride_of[g];
@@ -404,8 +405,8 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
 
   std::vector<ZhBlockDesc> &bd_sorted = P.bd_sorted;
   bd_sorted.reserve(sel.size());
-  size_t base_of[ZH_NFAM] = {};
-  for (uint32_t g = 0; g < ZH_NFAM; ++g) {
+  size_t base_of[ZH_NFAM_HOST] = {};
+  for (uint32_t g = 0; g < ZH_NFAM_HOST; ++g) {
     // Longest block first: the work queue then balances the tail (LPT order).
     std::stable_sort(groups[g].begin(), groups[g].end(), [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
     base_of[g] = bd_sorted.size();
@@ -417,7 +418,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
   HIPCHK(hipEventRecord(c->ev0, stream));
   if (side_by_side) HIPCHK(hipEventRecord(c->fork_ev, stream));      // the tables and descriptors above are on `stream`
   hipStream_t const launch_stream = stream;
-  for (uint32_t g = 0; g < ZH_NFAM; ++g) {
+  for (uint32_t g = 0; g < ZH_NFAM_HOST; ++g) {
     if (groups[g].empty()) continue;
     hipStream_t stream = launch_stream;                  // (shadows: the family's own stream when families run side by side)
     if (side_by_side) {
@@ -454,6 +455,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     else if (g == ZH_FAM_CM1 && prof) HIPCHK(zh_launch_cm_prof(&L, slots_of[g], stream));
     else if (g == ZH_FAM_CM1 && cm_x2[g]) HIPCHK(zh_launch_cm_x2(&L, slots_of[g] / 2, stream));
     else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, slots_of[g], stream));
+    else if (g == ZH_FAM_CHAIN_MID8) HIPCHK(zh_launch_nibble(&L, slots_of[g], stream, 5, prof));   // mid's shape, eight mixer inputs
 #ifdef ZH_WITH_CHAIN3
     else if (g > ZH_FAM_CHAIN && zh_chain3_has(g - ZH_FAM_CHAIN) && (opts.kernel == 7 || opts.kernel == 8))   // decoder ‖ model ‖ helper wave: experiment build only
       HIPCHK(zh_launch_chain3(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof ? 2 : opts.kernel == 7));
@@ -1186,6 +1188,7 @@ int zpaqhip_block_costs(const uint8_t *in, size_t in_len, const zpaqhip_block *b
         w = fam == ZH_FAM_STORE ? (pcomp ? 120u : 30u)                // zh_store.hip: wave-wide copy / LZ77 / inverse BWT
             : fam == ZH_FAM_CM1 ? kCm1Marker                         // zh_cm.hip: by coded / plain ratio, below
             : fam == ZH_FAM_CHAIN + 1 ? 3800u : fam == ZH_FAM_CHAIN + 2 ? 6800u : fam == ZH_FAM_CHAIN + 3 ? 16600u   // zh_nibble.hip min / mid, zh_chain2.hip max (profiles/r05)
+            : fam == ZH_FAM_CHAIN_MID8 ? 7000u                        // zh_nibble.hip, eight mixer inputs
             : fam == ZH_FAM_CHAIN ? 4000u + 2200u * m.n               // zh_chain.hip: level walk at run time
             : 10000u + 16000u * m.n;                                  // zh_generic.hip: one lane, tables in HBM
         if (pcomp && fam != ZH_FAM_STORE) w += w == kCm1Marker ? (uint64_t)-1 : 1500u;       // (marker - 1: single CM with a post-processor)

@@ -446,6 +446,15 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
       const uint8_t *mx = m.comp[7].arg;                                 // mix N 0 7 rate 255 over components 0..6
       if (ok4 && mx[1] == 0 && mx[2] == 7 && mx[4] == 255 && mx[0] >= 8) { spec = 2; method_model = true; }
     }
+    // ... and its text variant `ci1,1,1,1,2awm`: a word-model ICM as the eighth mixer input (H[8], the mixer's context, is
+    // never written by that program: the kernel takes it as 0)
+    bool mid8 = false;
+    if (spec == 0 && native == ZH_NATIVE_HCOMP_M4W && m.hh == 9 && m.hm == 16 && m.n == 9 && m.arena_bytes < (1ull << 31)) {
+      bool ok4 = m.comp[0].type == ZH_ICM && m.comp[6].type == ZH_MATCH && m.comp[7].type == ZH_ICM && m.comp[8].type == ZH_MIX;
+      for (uint32_t i = 1; ok4 && i <= 5; ++i) ok4 = m.comp[i].type == ZH_ISSE && m.comp[i].arg[1] == i - 1;
+      const uint8_t *mx = m.comp[8].arg;                                 // mix N 0 8 rate 255 over components 0..7
+      if (ok4 && mx[1] == 0 && mx[2] == 8 && mx[4] == 255 && mx[0] >= 8) mid8 = true;
+    }
     if (spec == 0 && native == ZH_NATIVE_HCOMP_M3 && m.hh == 9 && m.hm == 16 && m.n == 2 && m.arena_bytes < (1ull << 31) &&
         m.comp[0].type == ZH_ICM && m.comp[1].type == ZH_ISSE && m.comp[1].arg[1] == 0) {
       spec = 1; method_model = true;
@@ -459,6 +468,7 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
     // ... and it keeps H in 256 LDS words and M in one or two vector registers (256 / 512 bytes)
     if (spec && !method_model && (m.hh > 8 || m.hm > (spec == 3 ? 9u : 8u))) spec = 0;
     m.kind += spec;
+    if (mid8) m.kind = ZH_FAM_CHAIN_MID8;
     m.kind |= native << 8;
   }
   // Single direct CM whose HCOMP is "a<<= K  *d=a  halt" (D is 0 at every entry) with K >= 9: the low 9 bits of the

@@ -9,6 +9,10 @@
 #include "../../include/zpaqhip.h"
 #include "zh_model.h"
 
+// Kernel families known to the host only (the kernels never look at a family number): zh_model.h's, and
+#define ZH_FAM_CHAIN_MID8 7u     // zh_nibble.hip: mid's shape with EIGHT mixer inputs (icm, five isse, match, icm; mix) — the level-4 text model
+#define ZH_NFAM_HOST 8u
+
 namespace zh {
 
 // zh_tables.cpp — model-independent tables, generated and pinned against the

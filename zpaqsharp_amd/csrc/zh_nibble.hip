@@ -54,7 +54,19 @@ namespace {
 // — a slot is overwritten four / eight bytes after it was written, and both arrays start as zeros).  Their first line
 // stores C into H[(a + 255) & 511], a word no component reads (hh = 9, components read H[0 .. n-1]): the H view below
 // drops stores outside the words it stages.
+// The text variant of the level-4 model (`ci1,1,1,1,2awm`) has a word-model ICM as an eighth mixer input: mid's shape with
+// lane 7 an ICM and the MIX (component 8) without a lane — the mixer's sum is formed in every lane of a group anyway.  Its
+// context H[8] is a word the program (zh_native_hcomp_m4w) never writes: 0.
+struct NbMid8 {                                 // 0 icm ; 1-5 isse ; 6 match ; 7 icm ; 8 mix N 0 8 24 255
+  static constexpr uint32_t id = 6, n = 9, depth = 5, final_lane = 7, nmix = 1, hh = 3, hm = 3;
+  static constexpr uint64_t icm = 0x81, isse = 0x3e;
+  static constexpr int helper = 1;
+  static constexpr bool smem_ps = true, guard_rows = false, has_tail = false;
+  static constexpr int match_lane = 6;
+  static constexpr uint32_t mix_lane[2] = {8, 0}, mix_j0[2] = {0, 0}, mix_m[2] = {8, 0};
+};
 template <class SP> struct NbT { static constexpr uint32_t shape = SP::id; };
+template <> struct NbT<NbMid8> { static constexpr uint32_t shape = 2; };
 template <int NH>
 struct NbSpecH {                                // SpecH (zh_c2_common.h) that ignores words >= NH
   lds_u32_p base;
@@ -213,6 +225,8 @@ __device__ void nb_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       if constexpr (SP::id == 1) {
         if (hprog == ZH_NATIVE_HCOMP_M3) (void)zh_native_hcomp_m3(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, S.r, (Sink *)nullptr, L.budget);
         else (void)zh_native_hcomp_min(sa, sb, sc, sd, sf, x, sm, mmask_, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
+      } else if constexpr (SP::id == 6) {
+        (void)zh_native_hcomp_m4w(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, S.r, (Sink *)nullptr, L.budget);
       } else {
         if (hprog == ZH_NATIVE_HCOMP_M4) (void)zh_native_hcomp_m4(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, S.r, (Sink *)nullptr, L.budget);
         else (void)zh_native_hcomp_mid(sa, sb, sc, sd, sf, x, sm, mmask_, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
@@ -242,7 +256,7 @@ __device__ void nb_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       if (SP::nmix) {
         uint32_t hq = 0;
 #pragma unroll
-        for (uint32_t d = 0; d < NH; ++d) if ((SP::mix_lane[0] & (NH - 1u)) == d) hq = (uint32_t)sh[d];
+        for (uint32_t d = 0; d < NH; ++d) if (SP::mix_lane[0] == d) hq = (uint32_t)sh[d];      // (a MIX beyond the staged words: its context is 0, see NbMid8)
         const uint32_t row = mx_base + ((hq + mx_c1) & mx_size1) * (SP::mix_m[0] * 4u);
 #pragma unroll
         for (uint32_t t = 0; t < 4; ++t) {
@@ -755,7 +769,7 @@ __device__ __forceinline__ bool nb_boundary(const NbK<SP> &K, NbV &V, LDS &S, in
   }
   if (SP::nmix) {
     const uint32_t rb_was = V.mx_rb;
-    nb_mix_set(K, V, rdlane(V.hv, SP::mix_lane[0]));
+    nb_mix_set(K, V, SP::mix_lane[0] < NbK<SP>::NC ? rdlane(V.hv, SP::mix_lane[0] & 63u) : 0u);
     V.mwl[1] = K.l_feed ? (V.mx_rb == rb_was ? V.w1_new : sg_mw) : 0;
     nb_mix_rows(K, V, 1u);
   }
@@ -919,8 +933,11 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
         if constexpr (NbT<SP>::shape == 2) {
           const uint32_t mxb = uni(K.mx_base), mxs = uni(K.mx_size1), pmb = uni(lds_off(S.pm01));
           if constexpr (PROF) {
-            ZH_NB_FAST_MID_LOOP_PROF(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb, mxb, mxs, pmb);
+            if constexpr (SP::mix_m[0] == 8) { ZH_NB_FAST_MID8_LOOP_PROF(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb, mxb, mxs, pmb); }
+            else { ZH_NB_FAST_MID_LOOP_PROF(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb, mxb, mxs, pmb); }
             for (int i = 0; i < 12; ++i) P.prof[i] += S.fxa[kNmS_count + i][0];
+          } else if constexpr (SP::mix_m[0] == 8) {
+            ZH_NB_FAST_MID8_LOOP(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb, mxb, mxs, pmb);
           } else {
             ZH_NB_FAST_MID_LOOP(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb, mxb, mxs, pmb);
           }
@@ -1019,7 +1036,7 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
 template <class SP, bool PROF, class LDS>
 __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
   constexpr uint64_t kII = NbK<SP>::kII;
-  static_assert(SP::n <= NbK<SP>::NC && NbK<SP>::NC * NbK<SP>::NG <= 64, "lane budget");
+  static_assert(SP::n <= NbK<SP>::NC + (SP::nmix && SP::mix_lane[0] >= NbK<SP>::NC ? 1u : 0u) && NbK<SP>::NC * NbK<SP>::NG <= 64, "lane budget");
   NbProf P;
   for (int i = 0; i < 16; ++i) P.prof[i] = 0;
   P.tprev = 0;
@@ -1349,10 +1366,15 @@ ZH_NIBBLE_KERNEL(zh_decode_nb_min, C2Min, 2, false)
 ZH_NIBBLE_KERNEL(zh_decode_nb_mid, C2Mid, 6, false)
 ZH_NIBBLE_KERNEL(zh_decode_nb_min_prof, C2Min, 2, true)
 ZH_NIBBLE_KERNEL(zh_decode_nb_mid_prof, C2Mid, 6, true)
+ZH_NIBBLE_KERNEL(zh_decode_nb_mid8, NbMid8, 7, false)
+ZH_NIBBLE_KERNEL(zh_decode_nb_mid8_prof, NbMid8, 7, true)
 
-// spec: 1 min, 2 mid (zh_chain_spec.h ids; zh_framing.cpp also files the method models of their shapes under them)
+// spec: 1 min, 2 mid (zh_chain_spec.h ids; zh_framing.cpp also files the method models of their shapes under them), 5: mid's
+// shape with eight mixer inputs (ZH_FAM_CHAIN_MID8)
 extern "C" hipError_t zh_launch_nibble(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof) {
-  void (*k)(ZhLaunch) = spec == 1 ? (prof ? zh_decode_nb_min_prof : zh_decode_nb_min) : spec == 2 ? (prof ? zh_decode_nb_mid_prof : zh_decode_nb_mid) : nullptr;
+  void (*k)(ZhLaunch) = spec == 1 ? (prof ? zh_decode_nb_min_prof : zh_decode_nb_min)
+                        : spec == 2 ? (prof ? zh_decode_nb_mid_prof : zh_decode_nb_mid)
+                        : spec == 5 ? (prof ? zh_decode_nb_mid8_prof : zh_decode_nb_mid8) : nullptr;
   if (!k) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k, dim3(grid), dim3(128), 0, stream, *L);     // decoder wave + helper wave
   return hipGetLastError();
