@@ -203,18 +203,22 @@ def method_streams(z, synth, ctx, kib=4096, blocks=256, threads=None):
     from tools import methods
     bs = kib << 10
     out = []
-    # ... and (round 5) the MODELLED method strings real archives carry (LibZPAQ.makeConfig, LibZPAQ.cs:835-1041): their models are
-    # not the three built-in headers, so they run on the lane-per-component kernel of round 1 (zh_chain.hip) with their
-    # post-processor on one lane — 256 blocks of 64 KiB here: at 3-16 MB/s the default run must stay within minutes
-    for mt, what in (("x2,1,4,0,3,22", "lazy2: bit-packed LZ77, no model"), ("x2,2,12,0,7,22", "lzpre: byte-aligned LZ77, no model"),
-                     ("x3,3", "bwtrle: BWT, no model"),
-                     ("x0,2,12,0,7,16,1c0,0,511i2", "method 2: lzpre + icm/isse over the parse state"), ("x0,3ci1", "method 3: BWT + icm/isse"),
-                     ("x0,4ci1,1,1,1,2am", "method 4: E8E9 + icm/isse chain + match + mix"),
-                     ("x0,0c0,0,255w1i1c256ci1,1,1,1,1,1,2ac0,2,0,255i1c0,3,0,0,255i1c0,4,0,0,0,255i1mm16ts19t0", "method 5's recipe")):
+    # ... and (round 5) the MODELLED method strings real archives carry (LibZPAQ.compressBlock's choices, LibZPAQ.cs:196-260).  The
+    # BWT model of level 3 (`ci1`) and the level-4 models (`ci1,1,1,1,2am`, text: `...2awm`) have min's / mid's component lists:
+    # zh_nibble.hip decodes them (256 blocks of 256 KiB here).  The LZ77 + CM model of level 3 and the level-5 recipe run on
+    # the lane-per-component kernel of round 1 (zh_chain.hip) with their post-processor on one lane — 256 blocks of 64 KiB:
+    # at 3-16 MB/s the default run must stay within minutes
+    for mt, what, mkib in (("x2,1,4,0,3,22", "lazy2: bit-packed LZ77, no model", 0), ("x2,2,12,0,7,22", "lzpre: byte-aligned LZ77, no model", 0),
+                           ("x3,3", "bwtrle: BWT, no model", 0),
+                           ("x0,2,12,0,7,16,1c0,0,511i2", "level 3: lzpre + icm/isse over the parse state", 64),
+                           ("x0,3ci1", "level 3 / 4 on text: BWT + icm/isse", 256),
+                           ("x0,0ci1,1,1,1,2awm", "level 4 on text: icm/isse chain + match + word icm + mix", 256),
+                           ("x0,4ci1,1,1,1,2am", "level 4 on binaries: E8E9 + icm/isse chain + match + mix", 256),
+                           ("x0,0c0,0,255w1i1c256ci1,1,1,1,1,1,2ac0,2,0,255i1c0,3,0,0,255i1c0,4,0,0,0,255i1mm16ts19t0", "level 5's recipe", 64)):
         progress(f"method stream {mt[:24]}")
         model, margs = methods.model_of(mt)
         modelled = model.n > 0
-        bs = (64 << 10) if modelled else (kib << 10)
+        bs = (mkib << 10) if modelled else (kib << 10)
         s, _ = synth.method_stream(model, margs, "T", blocks, bs, threads=threads)
         got = ctx.decompress(s, out_cap=bs * blocks, verify_sha1=True)          # warm-up (arena allocation) + check
         ok = got.size == bs * blocks and all(np.array_equal(got[b * bs:(b + 1) * bs], synth.plain("T", b, bs)) for b in range(blocks))
@@ -223,7 +227,11 @@ def method_streams(z, synth, ctx, kib=4096, blocks=256, threads=None):
         ctx.decompress(s, out_cap=bs * blocks)
         dt = time.time() - t0
         kms = float(ctx.stats().kernel_ms)
-        out.append({"method": mt[:24], "what": what, "kernel": int(ctx.stats().kernel_kind), "block_KiB": bs >> 10,
+        # which decode kernel the host picks for this model, read off zpaqhip_block_costs (cycles per plaintext byte of the block's family)
+        per_byte = int(z.block_costs(s, z.scan(s))[0]) // bs
+        dev_kernel = {30: "zh_decode_store", 120: "zh_decode_store", 6800: "zh_decode_nb_mid", 7000: "zh_decode_nb_mid8", 3800: "zh_decode_nb_min",
+                      5300: "zh_decode_nb_min", 8300: "zh_decode_nb_mid", 8500: "zh_decode_nb_mid8"}.get(per_byte, "zh_decode_chain")
+        out.append({"method": mt[:24], "what": what, "kernel": int(ctx.stats().kernel_kind), "device_kernel": dev_kernel, "block_KiB": bs >> 10,
                     "workload": f"{blocks} x {bs >> 10} KiB distinct blocks, text-like plaintext, coded {s.size / 1e6:.0f} MB",
                     "value": (bs * blocks / dt / 1e6) if ok else 0.0, "unit": "MB/s (host to host)",
                     "kernel_ms": kms, "kernel_MBps": bs * blocks / (kms * 1e-3) / 1e6 if kms else None, "bit_exact": bool(ok)})
@@ -390,7 +398,7 @@ def compact_line(line):
         sh = line.get("cpu_share", {})
         out["cpu_share"] = [sh.get("host_logical_cores"), sh.get("affinity_cores"), sh.get("cgroup_cpu_quota_cores")]
     if "method_streams" in line:
-        out["method_streams"] = [{"method": m["method"], "kernel": m.get("kernel"), "KiB": m.get("block_KiB"), "value": _r(m["value"], 1),
+        out["method_streams"] = [{"method": m["method"], "kernel": m.get("device_kernel", m.get("kernel")), "KiB": m.get("block_KiB"), "value": _r(m["value"], 1),
                                   "kernel_MBps": _r(m["kernel_MBps"], 1), "bit_exact": m["bit_exact"]} for m in line["method_streams"]]
     if "other_configs" in line:                                  # last: one record per BASELINE-shaped configuration
         oc = []

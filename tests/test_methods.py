@@ -65,6 +65,73 @@ def test_method_streams_on_the_gpu(ctx, method):
         assert ctx.block_pcomp(s, 0)[2:] == m.pcomp
 
 
+# The models makeConfig writes for levels 3 (BWT) and 4 have min's / mid's component lists with other sizes and another
+# HCOMP: zh_nibble.hip decodes them (round 5), their post-processor fed from the chunks its assembly loop parks.
+NIBBLE_METHODS = ["x0,0ci1,1,1,1,2am", "x0,4ci1,1,1,1,2am", "x4,0ci1,1,1,1,2awm", "x0,4ci1,1,1,1,2awm", "x0,3ci1", "x0,7ci1", "x4,3ci1"]
+
+
+def test_method_models_join_the_families_of_min_and_mid():
+    """zh_framing.cpp files the level-4 model (`ci1,1,1,1,2am`) under mid's kernel family, its text variant (`...2awm`: a
+    word-model ICM as eighth mixer input) under a family of its own, the BWT model (`ci1`) under min's — whatever the
+    block-size argument makes of the table sizes; a chain of another length stays with the lane-per-component kernel.
+    Seen from outside through zpaqhip_block_costs: plaintext bytes x the family's cycles per byte (+ 1500 with PCOMP memory)."""
+    data = _data(5000)
+    per_byte = {"x0,0ci1,1,1,1,2am": 6800, "x6,4ci1,1,1,1,2am": 6800, "x0,0ci1,1,1,1,2awm": 7000, "x4,4ci1,1,1,1,2awm": 7000,
+                "x0,3ci1": 3800 + 1500, "x4,7ci1": 3800 + 1500, "x0,0ci1,1,1,2am": 4000 + 2200 * 7, "x0,0ci1,1,1,1,2a": 4000 + 2200 * 7}
+    for method, w in per_byte.items():
+        s = methods.compress_block(method, data)
+        sc = z.scan(s)
+        assert list(z.block_costs(s, sc)) == [len(data) * w], method
+    for name, w in (("mid", 6800), ("min", 3800)):
+        s = util.block(name, data)
+        assert list(z.block_costs(s, z.scan(s))) == [len(data) * w], name
+
+
+@pytest.mark.gpu
+def test_method_models_on_the_nibble_kernels(ctx):
+    """Every model of NIBBLE_METHODS on inputs that reach the assembly loop, its 256-byte chunks handed to the post-processor
+    (E8E9: translated; bwtrle: structurally matched; the rest of a chunk when the loop is left), short and empty blocks that
+    never reach it, runs and incompressible data — against the plaintext, the oracle and the lane-per-component kernel
+    (opts.kernel 4), which interprets the same HCOMP.  Then blocks of all of them and of the built-in min / mid in ONE stream:
+    the launches of mid's and min's families then hold blocks whose helper wave runs different programs."""
+    rng = np.random.default_rng(77)
+    cases = {"mixed": _data(150000), "text": util.text(70001, seed=8), "x86": util.x86ish(60000, 2), "tiny": b"Az", "empty": b"",
+             "runs": np.repeat(rng.integers(0, 256, 900, dtype=np.uint8), 41).tobytes(),
+             "random": rng.integers(0, 256, 30000, dtype=np.uint8).tobytes(), "words": b"the quick brown fox " * 2500}
+    for method in NIBBLE_METHODS:
+        for name, data in cases.items():
+            s = methods.compress_block(method, data)
+            if len(data) <= 70001:
+                assert oracle.decompress(s, cap=len(data) + 16) == data, (method, name)
+            for kernel in (0, 4):
+                assert ctx.decompress(s, verify_sha1=True, kernel=kernel, out_cap=len(data) + 16).tobytes() == data, (method, name, kernel)
+    parts = []
+    for i in range(3):
+        for method in NIBBLE_METHODS:
+            parts.append((methods.compress_block(method, _data(3000 + 977 * i + 13 * len(method))), _data(3000 + 977 * i + 13 * len(method))))
+        for name in ("mid", "min"):
+            d = util.text(5000 + 333 * i, seed=40 + i)
+            parts.append((util.block(name, d), d))
+    s = b"".join(p for p, _ in parts)
+    assert ctx.decompress(s, verify_sha1=True).tobytes() == b"".join(d for _, d in parts)
+    # a damaged stream: whatever the oracle makes of it (garbage into the post-processor, or an error)
+    good = methods.compress_block("x0,4ci1,1,1,1,2awm", cases["text"])
+    g = z.scan(good).segments[0]
+    for trial in range(6):
+        dmg = bytearray(good)
+        pos = int(g.data_off + rng.integers(40, g.data_len - 8))
+        dmg[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            want = ("ok", oracle.decompress(bytes(dmg), cap=1 << 20))
+        except oracle.OracleError as e:
+            want = ("err", str(e))
+        try:
+            got = ("ok", ctx.decompress(bytes(dmg)).tobytes())
+        except z.ZpaqError as e:
+            got = ("err", str(e))
+        assert got == want, (trial, pos)
+
+
 @pytest.mark.gpu
 def test_method_streams_multi_block(ctx):
     parts = [(mt, _data(4000 + 700 * i)) for i, mt in enumerate(METHODS[:7])]

@@ -29,6 +29,7 @@
 #include "zh_model.h"
 #include "zh_zpaql_native.h"
 #include "zh_zpaql_pcomp.h"
+#include "zh_ibwt.h"
 
 using namespace zhcore;
 using namespace zhdev;
@@ -802,7 +803,7 @@ __device__ __forceinline__ bool nb_boundary(const NbK<SP> &K, NbV &V, LDS &S, in
 //   2  error (fxs[kFxStatus])
 enum : int { kFxLow = 0, kFxHigh, kFxCurr, kFxK, kFxAvail, kFxBseq, kFxHelper, kFxWhy, kFxJ, kFxBad, kFxRn, kFxStatus, kFxModel, kFxWord, kFxRoom,
              kFxLenLo, kFxLenHi, kFxStoredLo, kFxStoredHi, kFxCapLo, kFxCapHi, kFxBaseLo, kFxBaseHi,
-             kFxPmode, kFxPnative, kFxPskel, kFxPa, kFxPb, kFxPc, kFxPd, kFxPf, kFxProf, kFxN = kFxProf + 36 };
+             kFxPmode, kFxPnative, kFxPskel, kFxPbwt, kFxPa, kFxPb, kFxPc, kFxPd, kFxPf, kFxProf, kFxN = kFxProf + 36 };
 static_assert(kFxN <= 96, "S.fxs");
 
 // ---- PostProcessor.write in state 5 (PostProcessor.cs:80-83) for the bytes nb_fast has decoded: the post-processor only
@@ -821,6 +822,17 @@ __device__ __attribute__((noinline)) int nb_pcomp_drain(const ZhLaunch *Lp_, LDS
   Vm &pz = S.pz;
   Sink &sink = S.sink;
   int rc = 0;
+  if (uni(S.fxs[kFxPbwt]) && (uint64_t)pb + (to - from) <= (uint64_t)uni(pz.mmask) + 1u) {
+    // bwtrle collects the segment in M (`a> 255 ifnot *b=a b++`): the chunk's bytes go there at once
+    const uint32_t lane = threadIdx.x & 63u;
+    uint8_t *Mw = reinterpret_cast<uint8_t *>(uni64((uint64_t)(uintptr_t)pz.m));
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      const uint32_t q = ((from & ~255u) + 4u * lane + i) - from;        // this lane's byte i, counted from `from`
+      if (q < to - from) Mw[pb + q] = (uint8_t)(park >> (8u * i));
+    }
+    if (to != from) { pa = (rdlane(park, ((to - 1u) >> 2) & 63u) >> (((to - 1u) & 3u) * 8u)) & 255u; pb += to - from; pf = 0; }
+  } else
   for (uint32_t p = from; p != to; ++p) {
     const uint32_t w = rdlane(park, (p >> 2) & 63u);
     const uint32_t c = (w >> ((p & 3u) * 8u)) & 255u;
@@ -1033,6 +1045,44 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+template <class LDS>
+__device__ __attribute__((noinline)) void nb_load_tables(const ZhLaunch &L, LDS &S, uint32_t lane) {
+  const ZhTables *T = L.tables;
+  for (uint32_t i = lane; i < 32768 / 8; i += 64) reinterpret_cast<uint4 *>(S.stretch)[i] = reinterpret_cast<const uint4 *>(T->stretch)[i];
+  for (uint32_t i = lane; i < 4096 / 8; i += 64) reinterpret_cast<uint4 *>(S.squash)[i] = reinterpret_cast<const uint4 *>(T->squash)[i];
+  for (uint32_t i = lane; i < 1024 / 16; i += 64) reinterpret_cast<uint4 *>(S.ns)[i] = reinterpret_cast<const uint4 *>(T->ns)[i];
+}
+template <class LDS>
+__device__ __attribute__((noinline)) void nb_load_pm01(const ZhLaunch &L, LDS &S, uint32_t lane) {
+  for (uint32_t i = lane; i < 256; i += 64) {            // the two predictions of a match of length i
+    const int dk = L.tables->dt2k[i];
+    const uint32_t lo = (uint16_t)S.stretch[dk & 32767], hi = (uint16_t)S.stretch[(-dk) & 32767];
+    S.pm01[i] = i ? lo | hi << 16 : 0u;
+  }
+}
+
+// The inverse BWT of the reference's bwtrle program at the end of a block's only segment, wave-wide (zh_ibwt.h) instead of the
+// program's one dependent load per byte.  Its tables overlay this block's stretch / squash / ns / pm01 / entry tables — the
+// model is finished (one segment) and the helper wave only polls its mailbox, which lies behind them — and are loaded again.
+typedef BwtLdsT<1024u> NbBwtLds;
+template <class LDS>
+__device__ __attribute__((noinline)) bool nb_ibwt(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t n_in, uint32_t *produced, bool *touched) {
+  static_assert(sizeof(NbBwtLds) <= offsetof(LDS, slot), "the inverse BWT's tables overlay the model's tables only");
+  Vm &pz = S.pz;
+  Sink &sink = S.sink;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  __builtin_amdgcn_s_waitcnt(0);
+  const uint64_t have = uni64(sink.len), cap = uni64(sink.cap);
+  const bool ok = ibwt_block<1024u>(*reinterpret_cast<NbBwtLds *>(&S), pz.m, pz.h, n_in, (uint64_t)uni(pz.mmask) + 1u, (uint64_t)uni(pz.hmask) + 1u,
+                                    sink.out + have, cap > have ? cap - have : 0u, produced, lane, touched);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  nb_load_tables(L, S, lane);
+  nb_wave_sync();
+  nb_load_pm01(L, S, lane);
+  nb_wave_sync();
+  return ok;
+}
+
 template <class SP, bool PROF, class LDS>
 __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
   constexpr uint64_t kII = NbK<SP>::kII;
@@ -1044,20 +1094,13 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
   const bool wave_a = (threadIdx.x >> 6) == 0;
 
   if (wave_a) {  // model-independent tables -> LDS
-    const ZhTables *T = L.tables;
-    for (uint32_t i = lane; i < 32768 / 8; i += 64) reinterpret_cast<uint4 *>(S.stretch)[i] = reinterpret_cast<const uint4 *>(T->stretch)[i];
-    for (uint32_t i = lane; i < 4096 / 8; i += 64) reinterpret_cast<uint4 *>(S.squash)[i] = reinterpret_cast<const uint4 *>(T->squash)[i];
-    for (uint32_t i = lane; i < 1024 / 16; i += 64) reinterpret_cast<uint4 *>(S.ns)[i] = reinterpret_cast<const uint4 *>(T->ns)[i];
+    nb_load_tables(L, S, lane);
     if (lane == 0) { S.zrow = v4u_{0, 0, 0, 0}; S.mb_cmd = 0; S.mb_ack = 0; S.mb_nib = 0; S.mb_byte = 0; S.mb_ready = 0; }
   }
   __syncthreads();                                       // the only workgroup barrier of the kernel
   if (!wave_a) { nb_helper<SP, LDS, PROF>(L, S, lane, blockIdx.x); return; }
   uint32_t cmd_seq = 0;
-  for (uint32_t i = lane; i < 256; i += 64) {            // the two predictions of a match of length i
-    const int dk = L.tables->dt2k[i];
-    const uint32_t lo = (uint16_t)S.stretch[dk & 32767], hi = (uint16_t)S.stretch[(-dk) & 32767];
-    S.pm01[i] = i ? lo | hi << 16 : 0u;
-  }
+  nb_load_pm01(L, S, lane);
   nb_wave_sync();
 
   uint8_t *slot_mem = L.arena + (uint64_t)blockIdx.x * L.arena_stride;
@@ -1143,6 +1186,7 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
     pz.r = S.pr;
     const bool p_lds = pz.m == S.pmreg && pz.h == S.phreg;
     uint32_t pnative = 0, pskel = 0;                    // the loaded program is the translated E8E9 / has the structure of one of zh_zpaql_pcomp.h's
+    uint32_t pbwt = 0;                                  // ... is the reference's bwtrle, operand for operand, in a block of one segment: M collects, nb_ibwt inverts
     uint32_t pa = 0, pb = 0, pc_ = 0, pd = 0, pf = 0;
     uint8_t *pzbuf = slot_mem + uni64(M->pz_off) + ZH_CODE_PAD;
     OutBuf sb;                                          // state 5: the cursor nb_fast parks decoded bytes under on their way to the program
@@ -1230,7 +1274,7 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
               S.fxs[kFxStoredLo] = (uint32_t)fo.stored; S.fxs[kFxStoredHi] = (uint32_t)(fo.stored >> 32);
               S.fxs[kFxCapLo] = (uint32_t)fo.cap; S.fxs[kFxCapHi] = (uint32_t)(fo.cap >> 32);
               S.fxs[kFxBaseLo] = (uint32_t)(uintptr_t)fo.base; S.fxs[kFxBaseHi] = (uint32_t)((uintptr_t)fo.base >> 32);
-              S.fxs[kFxPmode] = pp_state == 5; S.fxs[kFxPnative] = pnative; S.fxs[kFxPskel] = pskel;
+              S.fxs[kFxPmode] = pp_state == 5; S.fxs[kFxPnative] = pnative; S.fxs[kFxPskel] = pskel; S.fxs[kFxPbwt] = pbwt;
               S.fxs[kFxPa] = pa; S.fxs[kFxPb] = pb; S.fxs[kFxPc] = pc_; S.fxs[kFxPd] = pd; S.fxs[kFxPf] = pf;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1286,7 +1330,24 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
           if (LIKELY(c >= 0)) out_put(ob, (uint32_t)c, lane);
         } else if (pp_state == 5) {
           int rc;
-          if (pnative == ZH_NATIVE_PCOMP_E8E9)
+          bool done = false;
+          if (pbwt && c < 0) {                          // end of the block's only segment: the inverse BWT, wave-wide
+            uint32_t produced_b = 0;
+            bool touched = false;
+            if (nb_ibwt(L, S, lane, pb, &produced_b, &touched)) {
+              if (lane == 0) sink.len += uni(produced_b);
+              nb_wave_sync();
+              done = true;
+            } else if (touched) {                       // not a BWT after all: the program's own run wants its H as it left it (zeros)
+              uint32_t *Hz = reinterpret_cast<uint32_t *>(uni64((uint64_t)(uintptr_t)pz.h));
+              const uint64_t hw = (uint64_t)uni(pz.hmask) + 1u;
+              for (uint64_t i = lane; i < hw; i += 64) Hz[i] = 0;
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+              __builtin_amdgcn_s_waitcnt(0);
+            }
+          }
+          if (done) rc = 0;
+          else if (pnative == ZH_NATIVE_PCOMP_E8E9)
             rc = zh_native_pcomp_e8e9(pa, pb, pc_, pd, pf, (uint32_t)c, (lds_u8_p)lds_off(S.pmreg), pz.mmask, (lds_u32_p)lds_off(S.phreg), pz.hmask, S.pr, &sink, L.budget);
           else if (pskel) {
             ZhPcRegs r{pa, pb, pc_, pd, pf, 0};
@@ -1320,6 +1381,12 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
             pskel = pnative ? 0u : uni(zh_pcomp_lookup(pzbuf, pp_len));
             if (lane == 0) zh_pcomp_operands(pskel, pzbuf, S.pimm);
             nb_wave_sync();
+            if ((pskel == ZH_PCOMP_BWTRLE_123 || pskel == ZH_PCOMP_BWTRLE_106) && n_seg == 1u && !p_lds) {
+              const int nk = pskel == ZH_PCOMP_BWTRLE_123 ? 11 : 9;
+              bool same = true;
+              for (int k = 0; k < nk; ++k) same = same && uni(S.pimm[k]) == (pskel == ZH_PCOMP_BWTRLE_123 ? kBwt123[k] : kBwt106[k]);
+              pbwt = same ? 1u : 0u;
+            }
             pp_state = 5;
           }
         }
