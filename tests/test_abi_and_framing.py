@@ -255,3 +255,18 @@ def test_single_cm_byte_loop_keeps_its_branches_inside_their_fetch_windows():
         assert seen == 2
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_single_cm_family_stops_at_two_gib_tables():
+    """zh_cm.hip's swap wave addresses the table with 32-bit buffer offsets (window * 2048, a drop sentinel at 2 GiB): a single
+    CM of more than 2 GiB (cm 30 and up) keeps the family the general rules give it.  Seen through
+    zpaqhip_block_costs: the single-CM family costs ~1-2 thousand cycles per byte, the others 6 200 and up."""
+    from zpaqsharp_amd import zpaql
+    data = util.text(3000, seed=12)
+    per_byte = {}
+    for bits in (22, 29, 30):
+        m = zpaql.assemble(f"comp 0 0 0 0 1\n  0 cm {bits} 255\nhcomp\n  a<<= 9 *d=a halt\nend\n")
+        s = oracle.compress_block(m.header, data)
+        per_byte[bits] = int(z.block_costs(s, z.scan(s))[0]) // len(data)
+    assert per_byte[22] == per_byte[29] and per_byte[29] < 2100, per_byte
+    assert per_byte[30] >= 6200, per_byte
