@@ -30,6 +30,7 @@
 #include "zh_zpaql_native.h"
 #include "zh_zpaql_pcomp.h"
 #include "zh_ibwt.h"
+#include "zh_e8e9.h"
 
 using namespace zhcore;
 using namespace zhdev;
@@ -832,6 +833,20 @@ __device__ __attribute__((noinline)) int nb_pcomp_drain(const ZhLaunch *Lp_, LDS
       if (q < to - from) Mw[pb + q] = (uint8_t)(park >> (8u * i));
     }
     if (to != from) { pa = (rdlane(park, ((to - 1u) >> 2) & 63u) >> (((to - 1u) & 3u) * 8u)) & 255u; pb += to - from; pf = 0; }
+  } else if (pnative == ZH_NATIVE_PCOMP_E8E9 && uni(pz.mmask) == 0u) {
+    // E8E9 as the scalar operations it amounts to (zh_e8e9.h); its output parked and written like the decoder's own
+    const uint32_t lane = threadIdx.x & 63u;
+    OutBuf o;
+    o.base = reinterpret_cast<uint8_t *>(uni64((uint64_t)(uintptr_t)sink.out)); o.cap = uni64(sink.cap);
+    o.len = o.stored = uni64(sink.len); o.word = 0; o.park = 0;
+    out_room(o);
+    for (uint32_t p = from; p != to; ++p) {
+      const uint32_t w = rdlane(park, (p >> 2) & 63u);
+      uint32_t ob_;
+      if (zh_e8e9_step(pb, pc_, (w >> ((p & 3u) * 8u)) & 255u, ob_)) out_put(o, ob_, lane);
+    }
+    out_flush(o, lane);
+    if (lane == 0) sink.len = o.len;
   } else
   for (uint32_t p = from; p != to; ++p) {
     const uint32_t w = rdlane(park, (p >> 2) & 63u);
