@@ -205,12 +205,12 @@ def method_streams(z, synth, ctx, kib=4096, blocks=256, threads=None):
     out = []
     # ... and (round 5) the MODELLED method strings real archives carry (LibZPAQ.compressBlock's choices, LibZPAQ.cs:196-260).  The
     # BWT model of level 3 (`ci1`) and the level-4 models (`ci1,1,1,1,2am`, text: `...2awm`) have min's / mid's component lists:
-    # zh_nibble.hip decodes them (256 blocks of 256 KiB here).  The LZ77 + CM model of level 3 and the level-5 recipe run on
-    # the lane-per-component kernel of round 1 (zh_chain.hip) with their post-processor on one lane — 256 blocks of 64 KiB:
-    # at 3-16 MB/s the default run must stay within minutes
+    # and so has level 3's LZ77 + CM model (`...,1c0,0,511i2`): zh_nibble.hip decodes them (256 blocks of 256 KiB here).  The level-5
+    # recipe runs on the lane-per-component kernel of round 1 (zh_chain.hip) — 256 blocks of 64 KiB: at 3 MB/s the default run
+    # must stay within minutes
     for mt, what, mkib in (("x2,1,4,0,3,22", "lazy2: bit-packed LZ77, no model", 0), ("x2,2,12,0,7,22", "lzpre: byte-aligned LZ77, no model", 0),
                            ("x3,3", "bwtrle: BWT, no model", 0),
-                           ("x0,2,12,0,7,16,1c0,0,511i2", "level 3: lzpre + icm/isse over the parse state", 64),
+                           ("x0,2,12,0,7,16,1c0,0,511i2", "level 3: lzpre + icm/isse over the parse state", 256),
                            ("x0,3ci1", "level 3 / 4 on text: BWT + icm/isse", 256),
                            ("x0,0ci1,1,1,1,2awm", "level 4 on text: icm/isse chain + match + word icm + mix", 256),
                            ("x0,4ci1,1,1,1,2am", "level 4 on binaries: E8E9 + icm/isse chain + match + mix", 256),

@@ -214,6 +214,10 @@ def render_native() -> str:
     items.append(("hcomp_m4", zpaql.parse_header(methods.model_of("x0,0ci1,1,1,1,2am")[0].header)[5]))
     items.append(("hcomp_m3", zpaql.parse_header(methods.model_of("x0,3ci1")[0].header)[5]))
     items.append(("hcomp_m4w", zpaql.parse_header(methods.model_of("x0,0ci1,1,1,1,2awm")[0].header)[5]))
+    # level 3's LZ77 + CM model (`...,1c0,0,511i2`): the parse state lives in R1 / R2; one immediate follows the PCOMP's length
+    # (111 without, 168 with the E8E9 pass) — two exact programs, whatever the block-size argument
+    items.append(("hcomp_m2", zpaql.parse_header(methods.model_of("x0,2,12,0,7,21,1c0,0,511i2")[0].header)[5]))
+    items.append(("hcomp_m2e", zpaql.parse_header(methods.model_of("x0,6,12,0,7,21,1c0,0,511i2")[0].header)[5]))
     lines = ["// zh_zpaql_native.h — GENERATED by tools/gen_zpaql_native.py from zpaqsharp_amd/models.py; do not edit.",
              "// Native (ahead-of-time translated) forms of the ZPAQL programs this repo knows; see the generator.",
              "#pragma once", "#include <stdint.h>", "#include <string.h>", "", '#include "zh_core.h"', "",

@@ -330,7 +330,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     // families carry the built-in HCOMP programs
     if ((opts.kernel == 9 || opts.kernel == 7 || opts.kernel == 8 || opts.kernel == 5) && f > ZH_FAM_CHAIN && f < ZH_FAM_STORE) {
       const uint32_t hk = (models[bd[k].model].kind >> 8) & 255u;
-      if (hk == ZH_NATIVE_HCOMP_M4 || hk == ZH_NATIVE_HCOMP_M3) f = ZH_FAM_CHAIN;
+      if (hk == ZH_NATIVE_HCOMP_M4 || hk == ZH_NATIVE_HCOMP_M3 || hk == ZH_NATIVE_HCOMP_M2 || hk == ZH_NATIVE_HCOMP_M2E) f = ZH_FAM_CHAIN;
     }
     if ((opts.kernel == 9 || opts.kernel == 7 || opts.kernel == 8 || opts.kernel == 5 || opts.kernel == 4) && f == ZH_FAM_CHAIN_MID8) f = ZH_FAM_CHAIN;
     return f;

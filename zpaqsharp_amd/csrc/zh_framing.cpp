@@ -455,7 +455,7 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
       const uint8_t *mx = m.comp[8].arg;                                 // mix N 0 8 rate 255 over components 0..7
       if (ok4 && mx[1] == 0 && mx[2] == 8 && mx[4] == 255 && mx[0] >= 8) mid8 = true;
     }
-    if (spec == 0 && native == ZH_NATIVE_HCOMP_M3 && m.hh == 9 && m.hm == 16 && m.n == 2 && m.arena_bytes < (1ull << 31) &&
+    if (spec == 0 && (native == ZH_NATIVE_HCOMP_M3 || native == ZH_NATIVE_HCOMP_M2 || native == ZH_NATIVE_HCOMP_M2E) && m.hh == 9 && m.hm == 16 && m.n == 2 && m.arena_bytes < (1ull << 31) &&
         m.comp[0].type == ZH_ICM && m.comp[1].type == ZH_ISSE && m.comp[1].arg[1] == 0) {
       spec = 1; method_model = true;
     }

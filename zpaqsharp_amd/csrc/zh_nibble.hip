@@ -203,6 +203,7 @@ __device__ void nb_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       mx_base = uni((uint32_t)mc.cm_off); mx_size1 = uni(mc.cm_mask); mx_c1 = 1u & (uint32_t)mc.arg[4];
     }
     uint32_t hb = 0, hc = 0, hd = 0, hf = 0;              // committed HCOMP registers (A is the input at every run; M and H: S.mreg / S.hreg, zeroed by the decoder)
+    uint32_t hr1 = 0, hr2 = 0;                            // ... and R1 / R2 (the only R registers a program of these models uses)
     c2_put0(&S.mb_ack, cmd);
     uint32_t seq = 1;
     bool alive = true;
@@ -224,8 +225,11 @@ __device__ void nb_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       const SpecM sm{(lds_u8_p)lds_off(S.mreg), &wi, &wv, &wn};
       const NbSpecH<NH> sh{(lds_u32_p)lds_off(S.hreg), hs, &wmask};
       constexpr uint32_t mmask_ = (1u << SP::hm) - 1u;
+      uint32_t rl[3] = {0u, hr1, hr2};                  // R1 / R2 of the candidate's run (the LZ77 + CM model keeps its parse state there)
       if constexpr (SP::id == 1) {
         if (hprog == ZH_NATIVE_HCOMP_M3) (void)zh_native_hcomp_m3(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, S.r, (Sink *)nullptr, L.budget);
+        else if (hprog == ZH_NATIVE_HCOMP_M2) (void)zh_native_hcomp_m2(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, rl, (Sink *)nullptr, L.budget);
+        else if (hprog == ZH_NATIVE_HCOMP_M2E) (void)zh_native_hcomp_m2e(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, rl, (Sink *)nullptr, L.budget);
         else (void)zh_native_hcomp_min(sa, sb, sc, sd, sf, x, sm, mmask_, sh, NH - 1u, S.r, (Sink *)nullptr, L.budget);
       } else if constexpr (SP::id == 6) {
         (void)zh_native_hcomp_m4w(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, S.r, (Sink *)nullptr, L.budget);
@@ -304,6 +308,7 @@ __device__ void nb_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       if (PROF) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(hb_t0)::"memory"); hb_slack += hb_t0 - hb_t1; }
       const uint32_t lo = v & (kNbCand - 1u);
       hb = rdlane(sb, lo); hc = rdlane(sc, lo); hd = rdlane(sd, lo); hf = rdlane(sf, lo);
+      hr1 = rdlane(rl[1], lo); hr2 = rdlane(rl[2], lo);
       const uint32_t cwi = rdlane(wi, lo), cwv = rdlane(wv, lo), cwn = rdlane(wn, lo);
       if (cwn && lane == 0) S.mreg[cwi] = (uint8_t)cwv;
       if (lane < NH) { const uint32_t hv_ = S.hspec[lane][lo]; S.hreg[lane] = hv_; }
