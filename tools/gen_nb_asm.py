@@ -600,6 +600,38 @@ def gen():
     # a row written late lies in the probed bucket: the helper's three probes, patched, and find
     o(".p2align 5")
     label("near")
+    # A context that does not change from byte to byte (the order-0 ICM of the method models, h = 0) reads the very row this byte's
+    # first nibble used.  Predictor.find returns probe 0's place when the row there carries the context's check byte — and what
+    # lies there now is the row this wave wrote back (old1 at the nibble switch, oldb just now: the later store wins).  Lanes for
+    # which that holds take the row from the registers it was written from; only a lane whose late row lies at another place of
+    # the bucket, or under another check byte, needs the three probes patched and searched.
+    o(f"""
+      s_mov_b64 {S.M2}, vcc
+      v_lshrrev_b32_e32 {T[6]}, {R.k_sb2}, {T[4]}
+      v_and_b32_e32 {T[0]}, 0xff, {R.o1[0]}
+      v_and_b32_e32 {T[6]}, 0xff, {T[6]}
+      v_and_b32_e32 {T[2]}, 0xff, {R.ob[0]}
+      v_cmp_eq_u32_e32 vcc, {T[6]}, {T[0]}
+      v_cmp_eq_u32_e64 {S.M1}, {R.o1off}, {T[5]}
+      s_and_b64 {S.M1}, {S.M1}, vcc
+      v_cmp_eq_u32_e32 vcc, {T[6]}, {T[2]}
+      v_cmp_eq_u32_e64 {S.M0}, {R.oboff}, {T[5]}
+      s_and_b64 {S.M0}, {S.M0}, vcc
+      s_or_b64 vcc, {S.M0}, {S.M1}
+      s_andn2_b64 vcc, {S.M2}, vcc
+      s_cbranch_vccnz .Lnearfull_%=
+      v_cndmask_b32_e64 {row[0]}, {row[0]}, {R.o1[0]}, {S.M1}
+      v_cndmask_b32_e64 {row[1]}, {row[1]}, {R.o1[1]}, {S.M1}
+      v_cndmask_b32_e64 {row[2]}, {row[2]}, {R.o1[2]}, {S.M1}
+      v_cndmask_b32_e64 {row[3]}, {row[3]}, {R.o1[3]}, {S.M1}
+      v_cndmask_b32_e64 {sel}, {sel}, {T[5]}, {S.M1}
+      v_cndmask_b32_e64 {row[0]}, {row[0]}, {R.ob[0]}, {S.M0}
+      v_cndmask_b32_e64 {row[1]}, {row[1]}, {R.ob[1]}, {S.M0}
+      v_cndmask_b32_e64 {row[2]}, {row[2]}, {R.ob[2]}, {S.M0}
+      v_cndmask_b32_e64 {row[3]}, {row[3]}, {R.ob[3]}, {S.M0}
+      v_cndmask_b32_e64 {sel}, {sel}, {T[5]}, {S.M0}
+      s_branch .Ltaken_%=""")
+    label("nearfull")
     o(f"""
       v_lshrrev_b32_e32 {T[6]}, {R.k_sb2}, {T[4]}
       v_and_b32_e32 {T[6]}, 0xff, {T[6]}

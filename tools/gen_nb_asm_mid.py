@@ -63,7 +63,8 @@ S.mw = "s[46:47]"       # a mask temporary
 MIX_M = 7          # mixer inputs: 7 (mid: lane 7 is the MIX, whose context is h[7]) or 8 (the level-4 text model: lane 7 is an ICM, the
                    # MIX has no lane and its context h[8] is 0)
 PROF = False
-PROF_FINE = bool(int(os.environ.get('NB_PROF_FINE', '0')))     # diagnostic: three more stamps inside every level (9: chain done, 10: squash back, 11: decoded)
+PROF_FINE = int(os.environ.get('NB_PROF_FINE', '0')) == 1      # diagnostic: three more stamps inside every level (9: chain done, 10: squash back, 11: decoded)
+PROF_BND = int(os.environ.get('NB_PROF_FINE', '0')) == 2       # ... or inside the byte boundary (9: next byte's mixer rows requested, 10: this byte's stores issued, 11: MATCH settled)
 
 
 def stamp(i):
@@ -541,6 +542,8 @@ def gen():
       buffer_load_dword {R.mwl[3]}, {R.mrA[3]}, %[rs], 0 offen
       buffer_load_dword {R.mwl[4]}, {R.mrA[4]}, %[rs], 0 offen
       v_cndmask_b32_e64 {R.mwl[1]}, 0, {R.mwl[1]}, {S.mfeed}""")
+    if PROF_BND:
+        stamp(9)
     # ---- the stores of this byte, behind those loads: MATCH's history byte and hash index (Predictor.cs:386-410 with the h[] of
     # the byte just coded), the second nibble's row, its trained mixer weights
     o(f"""
@@ -549,6 +552,8 @@ def gen():
       v_add_u32_e32 {T[0]}, {R.k_evo}, {R.oboff}
       buffer_store_dwordx4 {R.ob4}, {T[0]}, %[rs], 0 offen""")
     mixer_stores(R.mrB)
+    if PROF_BND:
+        stamp(10)
     # ---- match_boundary (Predictor.cs:391-410); the history bytes it compares were requested at the nibble switch
     o(f"""
       v_sub_u32_e32 {T[0]}, {R.m_limit}, {R.cm_pre}
@@ -580,6 +585,8 @@ def gen():
       v_lshl_add_u32 {T[2]}, {T[2]}, 2, {R.k_cmo}
       v_cndmask_b32_e64 {T[2]}, {R.k_koob}, {T[2]}, {S.mmatch}
       buffer_load_dword {R.cm_pre}, {T[2]}, %[rs], 0 offen""")
+    if PROF_BND:
+        stamp(11)
     # ---- is one of the two rows written late in the bucket the helper probed?
     o(f"""
       v_add_u32_e32 {T[4]}, 16, {R.hv}
@@ -726,6 +733,40 @@ def gen():
     # ---- a row written late lies in the probed bucket: the helper's three probes, patched, and find
     o(".p2align 5")
     label("near")
+    # The common reason to be here is the ICM of order 0 (h = 0): the next byte's first nibble reads the very row this byte's first
+    # nibble used.  Predictor.find returns probe 0's place when the row there carries the context's check byte — and what lies
+    # there now is the row this wave wrote back (old1 at the nibble switch, oldb just now: the later store wins).  Lanes for
+    # which that holds take the row from the registers it was written from; only a lane whose late row lies at another place
+    # of the bucket, or under another check byte, needs the three probes patched and searched.
+    o(f"""
+      s_mov_b64 {S.M2}, vcc
+      v_lshrrev_b32_e32 {T[6]}, {R.k_sb2}, {T[4]}
+      v_and_b32_e32 {T[0]}, 0xff, {R.o1[0]}
+      v_and_b32_e32 {T[6]}, 0xff, {T[6]}
+      v_and_b32_e32 {T[2]}, 0xff, {R.ob[0]}
+      v_cmp_eq_u32_e32 vcc, {T[6]}, {T[0]}
+      v_cmp_eq_u32_e64 {S.M1}, {R.o1off}, {T[5]}
+      s_and_b64 {S.M1}, {S.M1}, vcc
+      v_cmp_eq_u32_e32 vcc, {T[6]}, {T[2]}
+      v_cmp_eq_u32_e64 {S.M0}, {R.oboff}, {T[5]}
+      s_and_b64 {S.M0}, {S.M0}, vcc
+      s_and_b64 {S.M1}, {S.M1}, {S.mii}
+      s_and_b64 {S.M0}, {S.M0}, {S.mii}
+      s_or_b64 vcc, {S.M0}, {S.M1}
+      s_andn2_b64 vcc, {S.M2}, vcc
+      s_cbranch_vccnz .Lnearfull_%=
+      v_cndmask_b32_e64 {row[0]}, {row[0]}, {R.o1[0]}, {S.M1}
+      v_cndmask_b32_e64 {row[1]}, {row[1]}, {R.o1[1]}, {S.M1}
+      v_cndmask_b32_e64 {row[2]}, {row[2]}, {R.o1[2]}, {S.M1}
+      v_cndmask_b32_e64 {row[3]}, {row[3]}, {R.o1[3]}, {S.M1}
+      v_cndmask_b32_e64 {sel}, {sel}, {T[5]}, {S.M1}
+      v_cndmask_b32_e64 {row[0]}, {row[0]}, {R.ob[0]}, {S.M0}
+      v_cndmask_b32_e64 {row[1]}, {row[1]}, {R.ob[1]}, {S.M0}
+      v_cndmask_b32_e64 {row[2]}, {row[2]}, {R.ob[2]}, {S.M0}
+      v_cndmask_b32_e64 {row[3]}, {row[3]}, {R.ob[3]}, {S.M0}
+      v_cndmask_b32_e64 {sel}, {sel}, {T[5]}, {S.M0}
+      s_branch .Ltaken_%=""")
+    label("nearfull")
     o(f"""
       v_lshrrev_b32_e32 {T[6]}, {R.k_sb2}, {T[4]}
       v_and_b32_e32 {T[6]}, 0xff, {T[6]}
