@@ -122,7 +122,9 @@ typedef struct zpaqhip_opts {
                                  7 / 8: ignored (= auto) by the product build; a library built with `make EXPERIMENTS=1` runs the
                                  measured-and-not-kept three-wave form of mid/max there (tools/experiments/zh_chain3.hip);
                                  9: the built-in min / mid models on the bit-at-a-time kernels of rounds 2-4 (zh_chain2.hip) instead of
-                                 the nibble-at-a-time ones (zh_nibble.hip): cross-check and A/B runs */
+                                 the nibble-at-a-time ones (zh_nibble.hip): cross-check and A/B runs.  The models LibZPAQ.makeConfig
+                                 writes for levels 3 / 4 (`ci1`, `...,1c0,0,511i2`, `ci1,1,1,1,2am`, `...2awm`) are known to
+                                 zh_nibble.hip only: under 4, 5 and 9 they run on the lane-per-component kernel */
   uint64_t zpaql_budget;      /* runaway-program guard, per run() call: max ZPAQL instructions on the interpreter, max backward
                                  jumps in an ahead-of-time translated program (a translation checks where it can loop);
                                  0 = default (1<<32).  Exceeding it ends the block with ZPAQHIP_E_BUDGET */

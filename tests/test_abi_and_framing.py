@@ -205,6 +205,25 @@ def test_nibble_kernel_loops_are_what_the_generator_laid_out():
         assert st["mix"].get("readfirstlane", 0) <= 1 and st["mix"].get("writelane", 0) <= 1, (mangled, st["mix"])
 
 
+def test_max_kernel_byte_loop_keeps_its_size():
+    """zh_chain2.hip's max kernel is compiler-rendered, and what the compiler makes of its byte loop depends on code far from
+    it: in round 5 two more HCOMP programs in zh_native_lookup — called once per block, when the PCOMP has arrived — took the
+    loop from 2 833 to 3 908 instructions per byte (36.9 -> 24.7 MB/s at 256 x 4 MiB) without a line of the kernel changing.
+    The kernels now ask zh_native_pcomp_lookup there; this pins the loop's size in the BUILT library (no GPU needed)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "zpaqsharp_amd", "libzpaqhip.so")
+    if not (os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") and os.path.exists(lib)):
+        pytest.skip("needs llvm-objdump and the built library")
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import count_instr
+    import loop_stats
+    funcs = count_instr.disassemble(lib)
+    ins = next(v for k, v in funcs.items() if k == "zh_decode_c2_max")
+    st = loop_stats.stats(ins, want=9)                   # eight bits and the EOS flag's step
+    assert st and st["steps"] == 9 and 2700 <= st["instr"] <= 3100, st      # (s_nop included: 2 937 for the 2 832 of profiles/r05)
+
+
 def test_single_cm_byte_loop_keeps_its_branches_inside_their_fetch_windows():
     """zh_cm_fast.h, rule 2 (profiles/r04/ab_notes.txt calls 22-26): a not-taken branch of the byte loop whose next
     two instructions do not lie in the branch's own 32-byte window costs ~19 cycles a time — 8 % between the best and the

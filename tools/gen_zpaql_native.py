@@ -248,6 +248,15 @@ def render_native() -> str:
         lines.append(f"  if (zh_native_is_{name}(prog, len)) return ZH_NATIVE_{name.upper()};")
     lines.append("  return 0;")
     lines.append("}")
+    lines.append("// ... among the post-processors only (what a kernel asks when a block's PCOMP has arrived: the comparisons against the")
+    lines.append("// HCOMP programs have no business in its code — zh_chain2.hip's max kernel grew from 2 833 to 3 908 instructions per byte")
+    lines.append("// when two more HCOMP programs joined the lookup above, round 5)")
+    lines.append("ZH_HD inline __attribute__((always_inline)) uint32_t zh_native_pcomp_lookup(const uint8_t *prog, uint32_t len) {")
+    for name, code in items:
+        if name.startswith("pcomp_"):
+            lines.append(f"  if (zh_native_is_{name}(prog, len)) return ZH_NATIVE_{name.upper()};")
+    lines.append("  return 0;")
+    lines.append("}")
     return "\n".join(lines) + "\n"
 
 

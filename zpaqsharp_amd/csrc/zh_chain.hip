@@ -707,7 +707,7 @@ __device__ __forceinline__ void decode_chain_body(const ZhLaunch &L, ChainLds &S
             __syncthreads();
             pz.prog = pzbuf; pz.len = pp_len;
             pz.a = pz.b = pz.c = pz.d = pz.f = 0;
-            pnative = p_lds ? uni(zh_native_lookup(pzbuf, pp_len)) : 0;
+            pnative = p_lds ? uni(zh_native_pcomp_lookup(pzbuf, pp_len)) : 0;
             if constexpr (PCALL) {
               pskel = pnative ? 0u : uni(zh_pcomp_lookup(pzbuf, pp_len));
               if (lane == 0) zh_pcomp_operands(pskel, pzbuf, S.pimm);

@@ -1045,7 +1045,7 @@ __device__ __forceinline__ void decode_chain2_body(const ZhLaunch &L, LDS &S) {
             c2_wave_sync();
             pz.prog = pzbuf; pz.len = pp_len;
             pz.a = pz.b = pz.c = pz.d = pz.f = 0;
-            pnative = p_lds ? uni(zh_native_lookup(pzbuf, pp_len)) : 0;
+            pnative = p_lds ? uni(zh_native_pcomp_lookup(pzbuf, pp_len)) : 0;
             pp_state = 5;
           }
         }

@@ -1397,7 +1397,7 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
             nb_wave_sync();
             pz.prog = pzbuf; pz.len = pp_len;
             pz.a = pz.b = pz.c = pz.d = pz.f = 0;
-            pnative = p_lds ? uni(zh_native_lookup(pzbuf, pp_len)) : 0;
+            pnative = p_lds ? uni(zh_native_pcomp_lookup(pzbuf, pp_len)) : 0;
             pskel = pnative ? 0u : uni(zh_pcomp_lookup(pzbuf, pp_len));
             if (lane == 0) zh_pcomp_operands(pskel, pzbuf, S.pimm);
             nb_wave_sync();
