@@ -68,7 +68,7 @@ def test_method_streams_on_the_gpu(ctx, method):
 # The models makeConfig writes for levels 3 (BWT) and 4 have min's / mid's component lists with other sizes and another
 # HCOMP: zh_nibble.hip decodes them (round 5), their post-processor fed from the chunks its assembly loop parks.
 NIBBLE_METHODS = ["x0,0ci1,1,1,1,2am", "x0,4ci1,1,1,1,2am", "x4,0ci1,1,1,1,2awm", "x0,4ci1,1,1,1,2awm", "x0,3ci1", "x0,7ci1", "x4,3ci1",
-                  "x0,2,12,0,7,21,1c0,0,511i2", "x4,6,12,0,7,25,1c0,0,511i2"]
+                  "x0,2,12,0,7,21,1c0,0,511i2", "x4,6,12,0,7,25,1c0,0,511i2", "x0,2,5,0,7,21,1c0,0,511", "x4,6,5,0,7,25,1c0,0,511"]
 
 
 def test_method_models_join_the_families_of_min_and_mid():
@@ -78,7 +78,8 @@ def test_method_models_join_the_families_of_min_and_mid():
     Seen from outside through zpaqhip_block_costs: plaintext bytes x the family's cycles per byte (+ 1500 with PCOMP memory)."""
     data = _data(5000)
     per_byte = {"x0,0ci1,1,1,1,2am": 6800, "x6,4ci1,1,1,1,2am": 6800, "x0,0ci1,1,1,1,2awm": 7000, "x4,4ci1,1,1,1,2awm": 7000,
-                "x0,3ci1": 3800 + 1500, "x4,7ci1": 3800 + 1500, "x0,2,12,0,7,21,1c0,0,511i2": 3800 + 1500, "x4,6,12,0,7,25,1c0,0,511i2": 3800 + 1500, "x0,0ci1,1,1,2am": 4000 + 2200 * 7, "x0,0ci1,1,1,1,2a": 4000 + 2200 * 7}
+                "x0,3ci1": 3800 + 1500, "x4,7ci1": 3800 + 1500, "x0,2,12,0,7,21,1c0,0,511i2": 3800 + 1500, "x4,6,12,0,7,25,1c0,0,511i2": 3800 + 1500,
+                "x0,2,5,0,7,21,1c0,0,511": 3800 + 1500, "x4,6,5,0,7,25,1c0,0,511": 3800 + 1500, "x0,2,5,0,7,21,1c0,0,255": 4000 + 2200 * 1 + 1500, "x0,0ci1,1,1,2am": 4000 + 2200 * 7, "x0,0ci1,1,1,1,2a": 4000 + 2200 * 7}
     for method, w in per_byte.items():
         s = methods.compress_block(method, data)
         sc = z.scan(s)

@@ -8,7 +8,7 @@ import zpaqsharp_amd as z
 from zpaqsharp_amd import synth
 from tools import methods
 
-METHODS = ["x0,0ci1,1,1,1,2awm", "x4,4ci1,1,1,1,2awm", "x0,0ci1,1,1,1,2am", "x0,4ci1,1,1,1,2am", "x0,3ci1", "x4,0ci1,1,1,1,2am", "x6,4ci1,1,1,1,2am", "x4,3ci1", "x0,7ci1", "x0,2,12,0,7,21,1c0,0,511i2", "x4,6,12,0,7,25,1c0,0,511i2"]
+METHODS = ["x0,0ci1,1,1,1,2awm", "x4,4ci1,1,1,1,2awm", "x0,0ci1,1,1,1,2am", "x0,4ci1,1,1,1,2am", "x0,3ci1", "x4,0ci1,1,1,1,2am", "x6,4ci1,1,1,1,2am", "x4,3ci1", "x0,7ci1", "x0,2,12,0,7,21,1c0,0,511i2", "x4,6,12,0,7,25,1c0,0,511i2", "x0,2,5,0,7,21,1c0,0,511", "x4,6,5,0,7,25,1c0,0,511"]
 
 
 def check(ctx):
@@ -33,7 +33,7 @@ def check(ctx):
 
 def rate(ctx, nb, kib):
     bs = kib << 10
-    for mt in METHODS[:5] + METHODS[-2:]:
+    for mt in METHODS[:5] + METHODS[-4:]:
         model, margs = methods.model_of(mt)
         t0 = time.time()
         s, _ = synth.method_stream(model, margs, "T", nb, bs, threads=16)

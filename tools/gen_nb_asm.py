@@ -80,6 +80,9 @@ S.M0, S.M1, S.M2 = "s[86:87]", "s[88:89]", "s[90:91]"      # FIND (the decoder t
 S.win = "s[100:101]"
 
 L = []          # output lines
+ICM_ONLY = False  # the MIN1 variant: the model is ONE ICM (level 4's form for barely compressible data); both lanes of a group are
+                  # that ICM (the second an exact replica: same constants, same reads, the same values written to the same places), so
+                  # no lane takes the ISSE half of the update — the only difference of the loop
 PROF = False    # the *_PROF variant: s_memtime stamps, cycles per stage summed in v100.. (lane-uniform), written out at exit
 
 
@@ -389,8 +392,8 @@ def gen():
     o(f"""
       s_mov_b32 s64, 0xff00ff00
       s_mov_b32 s65, 0xff00ff00
-      s_mov_b32 s66, 0xaaaaaaaa
-      s_mov_b32 s67, 0xaaaaaaaa
+      s_mov_b32 s66, {'0' if ICM_ONLY else '0xaaaaaaaa'}
+      s_mov_b32 s67, {'0' if ICM_ONLY else '0xaaaaaaaa'}
       s_mov_b32 s68, 0xffff
       s_mov_b32 s69, 0
       s_mov_b32 s70, 3
@@ -663,9 +666,10 @@ def gen():
       s_waitcnt lgkmcnt(0)""")
 
 
-def emit(name, prof):
-    global PROF
+def emit(name, prof, icm_only=False):
+    global PROF, ICM_ONLY
     PROF = prof
+    ICM_ONLY = icm_only
     del L[:]
     gen()
     clob = ["memory", "scc", "vcc"] + [f"s{i}" for i in range(60 if prof else 64, 102)] + [f"v{i}" for i in range(100 if prof else 128, 256)]
@@ -684,16 +688,19 @@ def emit(name, prof):
 def main():
     t0, n0 = emit("ZH_NB_FAST_MIN_LOOP", False)
     t1, _ = emit("ZH_NB_FAST_MIN_LOOP_PROF", True)
+    t2, _ = emit("ZH_NB_FAST_MIN1_LOOP", False, True)
+    t3, _ = emit("ZH_NB_FAST_MIN1_LOOP_PROF", True, True)
     head = f"""// zh_nb_fast.h — GENERATED by tools/gen_nb_asm.py (do not edit: edit the generator and run it).
 // The steady-state byte loop of nb_fast (zh_nibble.hip) for the built-in min model, hand-laid gfx950 assembly.
-// ZH_NB_FAST_MIN_LOOP_PROF is the same loop with s_memtime stamps (cycles per stage, kNbS_count + i of the state area).
+// ZH_NB_FAST_MIN_LOOP_PROF is the same loop with s_memtime stamps (cycles per stage, kNbS_count + i of the state area);
+// ZH_NB_FAST_MIN1_LOOP[_PROF] the loop for a model of one ICM (both lanes of a group are that ICM).
 #pragma once
 #define ZH_NB_FAST_MIN 1
 enum : int {{ {", ".join("kNbK_" + n + (" = 0" if i == 0 else "") for i, n in enumerate(KNAMES))}, kNbK_count }};
 enum : int {{ {", ".join("kNbS_" + n + (" = 0" if i == 0 else "") for i, n in enumerate(VNAMES))}, kNbS_count }};
 // clang-format off
 """
-    text = head + t0 + t1 + "// clang-format on\n"
+    text = head + t0 + t1 + t2 + t3 + "// clang-format on\n"
     if len(sys.argv) > 1 and sys.argv[1] == "--check":
         cur = open(OUT).read() if os.path.exists(OUT) else ""
         sys.exit(0 if cur == text else 1)

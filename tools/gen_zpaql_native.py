@@ -218,6 +218,9 @@ def render_native() -> str:
     # (111 without, 168 with the E8E9 pass) — two exact programs, whatever the block-size argument
     items.append(("hcomp_m2", zpaql.parse_header(methods.model_of("x0,2,12,0,7,21,1c0,0,511i2")[0].header)[5]))
     items.append(("hcomp_m2e", zpaql.parse_header(methods.model_of("x0,6,12,0,7,21,1c0,0,511i2")[0].header)[5]))
+    # ... and level 4's form for barely compressible data (`...,5,0,7,..,1c0,0,511`): the same program without the ISSE's context
+    items.append(("hcomp_m2s", zpaql.parse_header(methods.model_of("x0,2,5,0,7,21,1c0,0,511")[0].header)[5]))
+    items.append(("hcomp_m2se", zpaql.parse_header(methods.model_of("x0,6,5,0,7,21,1c0,0,511")[0].header)[5]))
     lines = ["// zh_zpaql_native.h — GENERATED by tools/gen_zpaql_native.py from zpaqsharp_amd/models.py; do not edit.",
              "// Native (ahead-of-time translated) forms of the ZPAQL programs this repo knows; see the generator.",
              "#pragma once", "#include <stdint.h>", "#include <string.h>", "", '#include "zh_core.h"', "",

@@ -96,7 +96,7 @@ namespace {
     }                                                                         \
   } while (0)
 
-constexpr size_t kQueueBytes = 256, kDebugBytes = 128;    // work-queue heads (32 B per family) and the *_prof kernels' sums
+constexpr size_t kQueueBytes = 512, kDebugBytes = 128;    // work-queue heads (32 B per family) and the *_prof kernels' sums
 constexpr uint64_t kPpOnlyMagic = 0x5A50505F4F4E4C59ull;   // internal: zpaqhip_block_pcomp -> decode_blocks_device ("ZPP_ONLY")
 
 zpaqhip_opts resolve_opts(const zpaqhip_opts *o) {
@@ -332,7 +332,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
       const uint32_t hk = (models[bd[k].model].kind >> 8) & 255u;
       if (hk == ZH_NATIVE_HCOMP_M4 || hk == ZH_NATIVE_HCOMP_M3 || hk == ZH_NATIVE_HCOMP_M2 || hk == ZH_NATIVE_HCOMP_M2E) f = ZH_FAM_CHAIN;
     }
-    if ((opts.kernel == 9 || opts.kernel == 7 || opts.kernel == 8 || opts.kernel == 5 || opts.kernel == 4) && f == ZH_FAM_CHAIN_MID8) f = ZH_FAM_CHAIN;
+    if ((opts.kernel == 9 || opts.kernel == 7 || opts.kernel == 8 || opts.kernel == 5 || opts.kernel == 4) && (f == ZH_FAM_CHAIN_MID8 || f == ZH_FAM_CHAIN_MIN1)) f = ZH_FAM_CHAIN;
     return f;
   };
   std::vector<std::vector<uint32_t>> groups(ZH_NFAM_HOST);
@@ -456,6 +456,7 @@ static int decode_launch(zpaqhip_ctx *c, const void *d_in, const uint8_t *h_in, 
     else if (g == ZH_FAM_CM1 && cm_x2[g]) HIPCHK(zh_launch_cm_x2(&L, slots_of[g] / 2, stream));
     else if (g == ZH_FAM_CM1) HIPCHK(zh_launch_cm(&L, slots_of[g], stream));
     else if (g == ZH_FAM_CHAIN_MID8) HIPCHK(zh_launch_nibble(&L, slots_of[g], stream, 5, prof));   // mid's shape, eight mixer inputs
+    else if (g == ZH_FAM_CHAIN_MIN1) HIPCHK(zh_launch_nibble(&L, slots_of[g], stream, 6, prof));   // one ICM on min's loop
 #ifdef ZH_WITH_CHAIN3
     else if (g > ZH_FAM_CHAIN && zh_chain3_has(g - ZH_FAM_CHAIN) && (opts.kernel == 7 || opts.kernel == 8))   // decoder ‖ model ‖ helper wave: experiment build only
       HIPCHK(zh_launch_chain3(&L, slots_of[g], stream, g - ZH_FAM_CHAIN, prof ? 2 : opts.kernel == 7));
@@ -1189,6 +1190,7 @@ int zpaqhip_block_costs(const uint8_t *in, size_t in_len, const zpaqhip_block *b
             : fam == ZH_FAM_CM1 ? kCm1Marker                         // zh_cm.hip: by coded / plain ratio, below
             : fam == ZH_FAM_CHAIN + 1 ? 3800u : fam == ZH_FAM_CHAIN + 2 ? 6800u : fam == ZH_FAM_CHAIN + 3 ? 16600u   // zh_nibble.hip min / mid, zh_chain2.hip max (profiles/r05)
             : fam == ZH_FAM_CHAIN_MID8 ? 7000u                        // zh_nibble.hip, eight mixer inputs
+            : fam == ZH_FAM_CHAIN_MIN1 ? 3800u                        // zh_nibble.hip, one ICM on min's loop
             : fam == ZH_FAM_CHAIN ? 4000u + 2200u * m.n               // zh_chain.hip: level walk at run time
             : 10000u + 16000u * m.n;                                  // zh_generic.hip: one lane, tables in HBM
         if (pcomp && fam != ZH_FAM_STORE) w += w == kCm1Marker ? (uint64_t)-1 : 1500u;       // (marker - 1: single CM with a post-processor)

@@ -467,8 +467,13 @@ int build_model(const uint8_t *hdr, size_t len, ZhModel &m, std::vector<uint8_t>
     if (spec == 2 && !method_model && (native != ZH_NATIVE_HCOMP_MID || m.hh != 3 || m.hm != 3)) spec = 0;
     // ... and it keeps H in 256 LDS words and M in one or two vector registers (256 / 512 bytes)
     if (spec && !method_model && (m.hh > 8 || m.hm > (spec == 3 ? 9u : 8u))) spec = 0;
+    // ... and level 4's model for barely compressible data, `...,5,0,7,..,1c0,0,511`: one ICM (the LZ77 + CM program without the
+    // ISSE's context)
+    const bool min1 = spec == 0 && !mid8 && (native == ZH_NATIVE_HCOMP_M2S || native == ZH_NATIVE_HCOMP_M2SE) && m.hh == 9 && m.hm == 16 &&
+                      m.n == 1 && m.comp[0].type == ZH_ICM && m.arena_bytes < (1ull << 31);
     m.kind += spec;
     if (mid8) m.kind = ZH_FAM_CHAIN_MID8;
+    if (min1) m.kind = ZH_FAM_CHAIN_MIN1;
     m.kind |= native << 8;
   }
   // Single direct CM whose HCOMP is "a<<= K  *d=a  halt" (D is 0 at every entry) with K >= 9: the low 9 bits of the

@@ -11,7 +11,8 @@
 
 // Kernel families known to the host only (the kernels never look at a family number): zh_model.h's, and
 #define ZH_FAM_CHAIN_MID8 7u     // zh_nibble.hip: mid's shape with EIGHT mixer inputs (icm, five isse, match, icm; mix) — the level-4 text model
-#define ZH_NFAM_HOST 8u
+#define ZH_FAM_CHAIN_MIN1 8u     // zh_nibble.hip: ONE ICM on min's loop — level 4's model for barely compressible data
+#define ZH_NFAM_HOST 9u
 
 namespace zh {
 

@@ -67,8 +67,23 @@ struct NbMid8 {                                 // 0 icm ; 1-5 isse ; 6 match ; 
   static constexpr int match_lane = 6;
   static constexpr uint32_t mix_lane[2] = {8, 0}, mix_j0[2] = {0, 0}, mix_m[2] = {8, 0};
 };
+// Level 4's model for barely compressible data (`...,5,0,7,..,1c0,0,511`) is ONE ICM over the LZ77 parse state.  It runs on min's
+// loop with both lanes of a group being that ICM: lane 1 has lane 0's constants, reads what lane 0 reads and writes the same
+// values to the same places (its entry table is a second copy that stays equal), so the lane the decoder reads (lane 1 of a
+// group) holds the ICM's prediction; no lane takes the ISSE half of the update (ZH_NB_FAST_MIN1_LOOP: an empty ISSE mask).
+struct NbMin1 {                                 // 0 icm N
+  static constexpr uint32_t id = 7, n = 1, depth = 1, final_lane = 1, nmix = 0, hh = 0, hm = 2;
+  static constexpr uint64_t icm = 0x3, isse = 0;
+  static constexpr int helper = 1;
+  static constexpr bool smem_ps = false, guard_rows = true, has_tail = false;
+  static constexpr int match_lane = -1;
+  static constexpr uint32_t mix_lane[2] = {0, 0}, mix_j0[2] = {0, 0}, mix_m[2] = {0, 0};
+};
 template <class SP> struct NbT { static constexpr uint32_t shape = SP::id; };
 template <> struct NbT<NbMid8> { static constexpr uint32_t shape = 2; };
+template <> struct NbT<NbMin1> { static constexpr uint32_t shape = 1; };
+// component a lane / unit index stands for (a replica lane stands for the last real component)
+template <class SP> __device__ constexpr uint32_t nb_comp_of(uint32_t ci) { return ci < SP::n ? ci : SP::n - 1u; }
 template <int NH>
 struct NbSpecH {                                // SpecH (zh_c2_common.h) that ignores words >= NH
   lds_u32_p base;
@@ -193,7 +208,7 @@ __device__ void nb_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       u_on[r] = u < NU;
       uint32_t ci = 0;
 #pragma unroll
-      for (uint32_t k = 0; k < NU; ++k) if (k == u) ci = c2_unit_comp<SP>(k);
+      for (uint32_t k = 0; k < NU; ++k) if (k == u) ci = nb_comp_of<SP>(c2_unit_comp<SP>(k));
       const ZhComp *cp = &M->comp[ci];
       u_comp[r] = ci; u_hto[r] = (uint32_t)cp->ht_off; u_mask[r] = cp->ht_mask; u_sb2[r] = (uint32_t)cp->arg[0] + 2u;
     }
@@ -226,7 +241,10 @@ __device__ void nb_helper(const ZhLaunch &L, LDS &S, uint32_t lane, uint32_t wg_
       const NbSpecH<NH> sh{(lds_u32_p)lds_off(S.hreg), hs, &wmask};
       constexpr uint32_t mmask_ = (1u << SP::hm) - 1u;
       uint32_t rl[3] = {0u, hr1, hr2};                  // R1 / R2 of the candidate's run (the LZ77 + CM model keeps its parse state there)
-      if constexpr (SP::id == 1) {
+      if constexpr (SP::id == 7) {
+        if (hprog == ZH_NATIVE_HCOMP_M2SE) (void)zh_native_hcomp_m2se(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, rl, (Sink *)nullptr, L.budget);
+        else (void)zh_native_hcomp_m2s(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, rl, (Sink *)nullptr, L.budget);
+      } else if constexpr (SP::id == 1) {
         if (hprog == ZH_NATIVE_HCOMP_M3) (void)zh_native_hcomp_m3(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, S.r, (Sink *)nullptr, L.budget);
         else if (hprog == ZH_NATIVE_HCOMP_M2) (void)zh_native_hcomp_m2(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, rl, (Sink *)nullptr, L.budget);
         else if (hprog == ZH_NATIVE_HCOMP_M2E) (void)zh_native_hcomp_m2e(sa, sb, sc, sd, sf, x, sm, mmask_, sh, 511u, rl, (Sink *)nullptr, L.budget);
@@ -384,7 +402,7 @@ __device__ __forceinline__ void nb_setup(NbK<SP> &K, LDS &S, const ZhModel *M, u
   K.ybit[0] = 0; K.ybit[1] = K.b1; K.ybit[2] = K.b2; K.ybit[3] = K.b3;     // the bit this group assumes at level d (d = 1..3)
   K.unit = (uint32_t)__builtin_popcountll(NbK<SP>::kII & ((1ull << K.ci) - 1));
   K.un_ = K.unit < c2_units<SP>() ? K.unit : 0u;
-  const ZhComp *mycp = &M->comp[K.ci < SP::n ? K.ci : 0];
+  const ZhComp *mycp = &M->comp[nb_comp_of<SP>(K.ci)];
   K.hto = K.l_ii || K.l_match ? (uint32_t)mycp->ht_off : 0u; K.ht_mask = mycp->ht_mask;
   K.cmo = (uint32_t)mycp->cm_off; K.cm_mask = mycp->cm_mask;
   K.sizebits2 = (uint32_t)mycp->arg[0] + 2;
@@ -974,8 +992,11 @@ __device__ __attribute__((noinline)) void nb_fast(const ZhLaunch *Lp_, LDS *Sp_)
             ZH_NB_FAST_MID_LOOP(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb, mxb, mxs, pmb);
           }
         } else if constexpr (PROF) {
-          ZH_NB_FAST_MIN_LOOP_PROF(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb);
+          if constexpr (SP::isse == 0) { ZH_NB_FAST_MIN1_LOOP_PROF(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb); }
+          else { ZH_NB_FAST_MIN_LOOP_PROF(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb); }
           for (int i = 0; i < 12; ++i) P.prof[i] += S.fxa[kNbS_count + i][0];
+        } else if constexpr (SP::isse == 0) {
+          ZH_NB_FAST_MIN1_LOOP(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb);
         } else {
           ZH_NB_FAST_MIN_LOOP(lo_, hi_, cu_, k_, bseq, nput, room, word, asm_why, obad, ofail, m0s, klim_s, vlo_s, kb, vb, rs, sqb, nsb);
         }
@@ -1172,7 +1193,7 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
         const v2u e_icm = {cinit, (uint32_t)stv};
         const v2u e_isse = {1u << 15, (uint32_t)clamp512k(stv * 1024)};
         uint32_t u = 0;
-        for (uint32_t i = 0; i < SP::n; ++i) {
+        for (uint32_t i = 0; i < NbK<SP>::NC; ++i) {     // (lanes beyond the model's components are replicas: NbMin1)
           if (!((kII >> i) & 1)) continue;
           S.ent[u][j] = ((SP::icm >> i) & 1) ? e_icm : e_isse;
           ++u;
@@ -1455,13 +1476,16 @@ ZH_NIBBLE_KERNEL(zh_decode_nb_min_prof, C2Min, 2, true)
 ZH_NIBBLE_KERNEL(zh_decode_nb_mid_prof, C2Mid, 6, true)
 ZH_NIBBLE_KERNEL(zh_decode_nb_mid8, NbMid8, 7, false)
 ZH_NIBBLE_KERNEL(zh_decode_nb_mid8_prof, NbMid8, 7, true)
+ZH_NIBBLE_KERNEL(zh_decode_nb_min1, NbMin1, 2, false)
+ZH_NIBBLE_KERNEL(zh_decode_nb_min1_prof, NbMin1, 2, true)
 
 // spec: 1 min, 2 mid (zh_chain_spec.h ids; zh_framing.cpp also files the method models of their shapes under them), 5: mid's
-// shape with eight mixer inputs (ZH_FAM_CHAIN_MID8)
+// shape with eight mixer inputs (ZH_FAM_CHAIN_MID8), 6: one ICM on min's loop (ZH_FAM_CHAIN_MIN1)
 extern "C" hipError_t zh_launch_nibble(const ZhLaunch *L, uint32_t grid, hipStream_t stream, uint32_t spec, int prof) {
   void (*k)(ZhLaunch) = spec == 1 ? (prof ? zh_decode_nb_min_prof : zh_decode_nb_min)
                         : spec == 2 ? (prof ? zh_decode_nb_mid_prof : zh_decode_nb_mid)
-                        : spec == 5 ? (prof ? zh_decode_nb_mid8_prof : zh_decode_nb_mid8) : nullptr;
+                        : spec == 5 ? (prof ? zh_decode_nb_mid8_prof : zh_decode_nb_mid8)
+                        : spec == 6 ? (prof ? zh_decode_nb_min1_prof : zh_decode_nb_min1) : nullptr;
   if (!k) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k, dim3(grid), dim3(128), 0, stream, *L);     // decoder wave + helper wave
   return hipGetLastError();
