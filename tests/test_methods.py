@@ -143,7 +143,8 @@ def test_method_streams_multi_block(ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("method", ["x0,1,4,0,3,16", "x6,1,4,0,3,24", "x0,5,4,0,3,16", "x6,5,4,0,3,24", "x0,2,12,0,7,16",
-                                    "x0,6,5,0,3,16c0,0,511", "x0,4ci1,1,1,1,2am", "x0,3ci1", "x0,7ci1"])
+                                    "x0,6,5,0,3,16c0,0,511", "x0,4ci1,1,1,1,2am", "x0,3ci1", "x0,7ci1",
+                                    "x0,2,12,0,7,21,1c0,0,511i2", "x0,2,5,0,7,21,1c0,0,511"])
 def test_translated_pcomps_on_arbitrary_input(ctx, method):
     """The ahead-of-time translations (zh_zpaql_pcomp.h) must do what the interpreter does on ANY input, not only on
     well-formed LZ77 code: the post-processor is fed bytes no encoder would write, and the device's output (or its

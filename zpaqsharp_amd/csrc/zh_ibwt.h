@@ -11,6 +11,8 @@ using zhdev::uni;
 
 // operands of the reference's two bwtrle programs (zh_zpaql_pcomp.h lists the disassembly; zh_store.hip says why every operand
 // is compared): blocks up to 16 MiB / any size
+// ... and of its lzpre program (LibZPAQ.cs:575-639)
+__device__ const uint8_t kLzpre108[12] = {255, 0, 6, 1, 63, 0 /* minimum match */, 1, 0, 2, 8, 8, 0};
 __device__ const uint8_t kBwt123[11] = {255, 8, 8, 8, 0, 255, 1, 255, 8, 0, 8};
 __device__ const uint8_t kBwt106[9] = {255, 8, 8, 8, 0, 255, 1, 255, 0};
 

@@ -827,7 +827,7 @@ __device__ __forceinline__ bool nb_boundary(const NbK<SP> &K, NbV &V, LDS &S, in
 //   2  error (fxs[kFxStatus])
 enum : int { kFxLow = 0, kFxHigh, kFxCurr, kFxK, kFxAvail, kFxBseq, kFxHelper, kFxWhy, kFxJ, kFxBad, kFxRn, kFxStatus, kFxModel, kFxWord, kFxRoom,
              kFxLenLo, kFxLenHi, kFxStoredLo, kFxStoredHi, kFxCapLo, kFxCapHi, kFxBaseLo, kFxBaseHi,
-             kFxPmode, kFxPnative, kFxPskel, kFxPbwt, kFxPa, kFxPb, kFxPc, kFxPd, kFxPf, kFxProf, kFxN = kFxProf + 36 };
+             kFxPmode, kFxPnative, kFxPskel, kFxPbwt, kFxPlz, kFxPa, kFxPb, kFxPc, kFxPd, kFxPf, kFxProf, kFxN = kFxProf + 36 };
 static_assert(kFxN <= 96, "S.fxs");
 
 // ---- PostProcessor.write in state 5 (PostProcessor.cs:80-83) for the bytes nb_fast has decoded: the post-processor only
@@ -856,6 +856,63 @@ __device__ __attribute__((noinline)) int nb_pcomp_drain(const ZhLaunch *Lp_, LDS
       if (q < to - from) Mw[pb + q] = (uint8_t)(park >> (8u * i));
     }
     if (to != from) { pa = (rdlane(park, ((to - 1u) >> 2) & 63u) >> (((to - 1u) & 3u) * 8u)) & 255u; pb += to - from; pf = 0; }
+  } else if (uni(S.fxs[kFxPlz])) {
+    // The reference's lzpre (LibZPAQ.cs:575-639; zh_native_pcomp_lzpre_108 is its instruction-for-instruction translation) as the
+    // state machine it is — D: 0 code byte / 1 literals / 3..5 offset bytes to come / 2 last offset byte; R1: literals or match
+    // bytes left; R2: the offset so far; B: the write position in M — with a match copied by the wave: lane i takes byte i of a
+    // chunk of up to 64 (the program: one dependent load per byte on one lane).  A match that overlaps its source (distance <
+    // length) is periodic with the distance: a chunk reads at a multiple of the distance that the bytes written so far cover.
+    // M is written as the program writes it (later matches and the program's own runs — the general path's bytes, the end of a
+    // segment — find it as they expect); loads of M go to L2 (glc): the bytes may have been written by other lanes a moment ago.
+    const uint32_t lane = threadIdx.x & 63u, minlen = uni(S.fxs[kFxPlz]) - 1u, mm = uni(pz.mmask);
+    uint8_t *Mw = reinterpret_cast<uint8_t *>(uni64((uint64_t)(uintptr_t)pz.m));
+    uint32_t r1 = uni(S.pr[1]), r2 = uni(S.pr[2]);
+    OutBuf o;
+    o.base = reinterpret_cast<uint8_t *>(uni64((uint64_t)(uintptr_t)sink.out)); o.cap = uni64(sink.cap);
+    o.len = o.stored = uni64(sink.len); o.word = 0; o.park = 0;
+    out_room(o);
+    for (uint32_t p = from; p != to; ++p) {
+      const uint32_t w = rdlane(park, (p >> 2) & 63u);
+      const uint32_t x = (w >> ((p & 3u) * 8u)) & 255u;
+      if (pd == 0u) {
+        pd = (x >> 6) + 1u;
+        if (pd == 1u) r1 = x + 1u; else { ++pd; r1 = (x & 63u) + minlen; }
+        r2 = 0;
+      } else if (pd == 1u) {
+        if (lane == 0) Mw[pb & mm] = (uint8_t)x;
+        ++pb;
+        out_put(o, x, lane);
+        if (--r1 == 0u) pd = 0;
+      } else if (pd > 2u) {
+        r2 = r2 << 8 | x;
+        --pd;
+      } else {
+        r2 = r2 << 8 | x;
+        const uint32_t n = r1, dist = r2 + 1u;
+        out_flush(o, lane);                              // the literals parked so far
+        __builtin_amdgcn_s_waitcnt(0);                   // (their stores to M, too)
+        uint32_t done = 0, deff = dist;
+        while (done < n) {
+          uint32_t m = n - done;
+          m = m < 64u ? m : 64u;
+          m = m < deff ? m : deff;
+          if (lane < m) {
+            const uint8_t v = __hip_atomic_load(&Mw[(pb + done + lane - deff) & mm], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            Mw[(pb + done + lane) & mm] = v;
+            if (o.len + done + lane < o.cap) o.base[o.len + done + lane] = v;
+          }
+          done += m;
+          __builtin_amdgcn_s_waitcnt(0);
+          if (deff < 64u && 2u * deff <= done + dist) deff *= 2u;
+        }
+        pb += n;
+        o.len += n; o.stored = o.len; o.word = 0;
+        out_room(o);
+        pd = 0;
+      }
+    }
+    out_flush(o, lane);
+    if (lane == 0) { sink.len = o.len; S.pr[1] = r1; S.pr[2] = r2; }
   } else if (pnative == ZH_NATIVE_PCOMP_E8E9 && uni(pz.mmask) == 0u) {
     // E8E9 as the scalar operations it amounts to (zh_e8e9.h); its output parked and written like the decoder's own
     const uint32_t lane = threadIdx.x & 63u;
@@ -1228,6 +1285,7 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
     const bool p_lds = pz.m == S.pmreg && pz.h == S.phreg;
     uint32_t pnative = 0, pskel = 0;                    // the loaded program is the translated E8E9 / has the structure of one of zh_zpaql_pcomp.h's
     uint32_t pbwt = 0;                                  // ... is the reference's bwtrle, operand for operand, in a block of one segment: M collects, nb_ibwt inverts
+    uint32_t plz = 0;                                   // ... is the reference's lzpre, operand for operand (1 + its minimum match length): nb_pcomp_drain's state machine
     uint32_t pa = 0, pb = 0, pc_ = 0, pd = 0, pf = 0;
     uint8_t *pzbuf = slot_mem + uni64(M->pz_off) + ZH_CODE_PAD;
     OutBuf sb;                                          // state 5: the cursor nb_fast parks decoded bytes under on their way to the program
@@ -1315,7 +1373,7 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
               S.fxs[kFxStoredLo] = (uint32_t)fo.stored; S.fxs[kFxStoredHi] = (uint32_t)(fo.stored >> 32);
               S.fxs[kFxCapLo] = (uint32_t)fo.cap; S.fxs[kFxCapHi] = (uint32_t)(fo.cap >> 32);
               S.fxs[kFxBaseLo] = (uint32_t)(uintptr_t)fo.base; S.fxs[kFxBaseHi] = (uint32_t)((uintptr_t)fo.base >> 32);
-              S.fxs[kFxPmode] = pp_state == 5; S.fxs[kFxPnative] = pnative; S.fxs[kFxPskel] = pskel; S.fxs[kFxPbwt] = pbwt;
+              S.fxs[kFxPmode] = pp_state == 5; S.fxs[kFxPnative] = pnative; S.fxs[kFxPskel] = pskel; S.fxs[kFxPbwt] = pbwt; S.fxs[kFxPlz] = plz;
               S.fxs[kFxPa] = pa; S.fxs[kFxPb] = pb; S.fxs[kFxPc] = pc_; S.fxs[kFxPd] = pd; S.fxs[kFxPf] = pf;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1427,6 +1485,12 @@ __device__ __forceinline__ void decode_nibble_body(const ZhLaunch &L, LDS &S) {
               bool same = true;
               for (int k = 0; k < nk; ++k) same = same && uni(S.pimm[k]) == (pskel == ZH_PCOMP_BWTRLE_123 ? kBwt123[k] : kBwt106[k]);
               pbwt = same ? 1u : 0u;
+            }
+            if (pskel == ZH_PCOMP_LZPRE_108 && !p_lds && pz.m != S.pmreg) {
+              bool same = true;
+              for (int k = 0; k < 12; ++k) same = same && (k == 5 || uni(S.pimm[k]) == kLzpre108[k]);
+              const uint32_t minlen = uni(S.pimm[5]);
+              plz = (same && minlen >= 1u) ? minlen + 1u : 0u;
             }
             pp_state = 5;
           }

@@ -119,7 +119,7 @@ __device__ __forceinline__ int rd_chunk(Rd &r, StoreLds &S, uint32_t lane) {
 
 // operands of the reference's programs (zh_zpaql_pcomp.h lists the disassembly): a block whose program differs in ANY
 // operand that is not a parameter of the method is not taken here
-__device__ const uint8_t kLzpre108[12] = {255, 0, 6, 1, 63, 0 /* minimum match */, 1, 0, 2, 8, 8, 0};
+// (kLzpre108: zh_ibwt.h, shared with zh_nibble.hip)
 __device__ const uint8_t kLazy302[43] = {255, 8, 0, 1, 3, 0, 3, 2, 7, 3, 5, 1, 2, 3, 1, 2, 1, 1, 1, 1, 1, 1, 2, 3, 2, 2,
                                           2, 1, 0, 3, 1, 1, 1, 1, 1, 1, 1, 4, 4, 7, 8, 8, 0};
 // lazy2 with rb > 0 (blocks over 16 MiB): [26..35] = 5, rb-1, (1<<rb)-1, rb, rb, 2, 2, 1, rb, (1<<rb)-1
