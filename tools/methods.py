@@ -633,7 +633,7 @@ def bwt_level3(data: bytes) -> bytes:
         r2 = np.full(n, -1, np.int64)
         r2[:n - k] = rank[k:]
         order = np.lexsort((r2, rank))
-        key = rank[order] * (n + 2) + (r2[order] + 1)
+        key = rank[order] * (max(n, 256) + 2) + (r2[order] + 1)      # (ranks start as byte values: the radix must exceed 256 for blocks shorter than that)
         nr = np.zeros(n, np.int64)
         nr[order] = np.concatenate([[0], np.cumsum(key[1:] != key[:-1])])
         rank, sa = nr, order
