@@ -1,4 +1,4 @@
-"""For every stream under tools/experiments/fuzz_fail/: which block decodes differently by the host's kernel choice (kernel=0) and by
+"""For every stream under tools/experiments/fuzz_fail/ (copy gpurun_out/fuzz_fail_*.bin there): which block decodes differently by the host's kernel choice (kernel=0) and by
 the lane-per-component kernel (kernel=4), and where the outputs first differ."""
 import glob, hashlib, os, sys
 import numpy as np
