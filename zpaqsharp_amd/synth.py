@@ -189,6 +189,9 @@ def method_stream(model, args, kind: str = "T", nblocks: int = 1, block_size: in
     L = load()
     hdr, pc = _u8(model.header), _u8(model.pcomp or b"")
     a = (C.c_int * 9)(*[int(x) for x in list(args)[:9]] + [0] * (9 - min(9, len(args))))
+    if (int(a[1]) & 3) == 3 and model.pcomp and block_size + 5 > (1 << model.header[5]):
+        # (compressBlock never writes such a block; bwtrle's walk over a wrapped M need not end before its instruction budget)
+        raise ValueError(f"a BWT block of {block_size} bytes does not fit the post-processor's M (2^{model.header[5]} bytes)")
     if threads is None:
         threads = min(32, os.cpu_count() or 1)
     h = L.zpaqgen_method_stream_new(hdr.ctypes.data, hdr.size, pc.ctypes.data if pc.size else None, pc.size, a, KINDS[kind],
