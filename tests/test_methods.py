@@ -301,3 +301,53 @@ def test_a_bwt_block_over_16_mib(ctx):
     got = ctx.decompress(s, out_cap=n, verify_sha1=True)
     assert ctx.stats().launches == 1
     assert np.array_equal(got, synth.plain("T", 0, n))
+
+
+def test_scalar_e8e9_is_the_reference_program(tmp_path):
+    """zh_e8e9.h states the reference's E8E9 post-processor (LibZPAQ.cs:802-826) as the few scalar operations it amounts to per
+    byte (B, C are all its state); zh_nibble.hip's drain runs that instead of the translated program.  Here the header is compiled
+    for the host and fed what the oracle's interpreter is fed: random bytes, bytes dense in E8 / E9 opcodes with 00 / FF top
+    bytes (every branch of the program), short inputs (fewer bytes than the program holds back) — same output byte for byte,
+    including what the program's own end-of-segment run flushes from the (B, C) the scalar form leaves."""
+    import ctypes
+    import os
+    import shutil
+    import subprocess
+    from zpaqsharp_amd import models
+    if not shutil.which("g++"):
+        pytest.skip("needs g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "e8.cpp"
+    src.write_text('#include <stdint.h>\n#define __device__\n#define __forceinline__ inline\n'
+                   f'#include "{root}/zpaqsharp_amd/csrc/zh_e8e9.h"\n'
+                   'extern "C" uint32_t e8_run(const uint8_t *in, uint32_t n, uint8_t *out, uint32_t *B, uint32_t *C) {\n'
+                   '  uint32_t k = 0, ob;\n'
+                   '  for (uint32_t i = 0; i < n; ++i) if (zh_e8e9_step(*B, *C, in[i], ob)) out[k++] = (uint8_t)ob;\n'
+                   '  return k;\n}\n')
+    so = tmp_path / "e8.so"
+    subprocess.run(["g++", "-O1", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    lib = ctypes.CDLL(str(so))
+    lib.e8_run.restype = ctypes.c_uint32
+    pcomp = models.E8E9 if hasattr(models, "E8E9") else models.get("max+e8e9").pcomp
+    rng = np.random.default_rng(88)
+    cases = [b"", b"\xe8", b"\xe8\x01\x02\x03", b"\xe8\x01\x02\x03\x00", rng.integers(0, 256, 5000, dtype=np.uint8).tobytes(),
+             util.x86ish(20000, 3)]
+    dense = bytearray(rng.integers(0, 256, 6000, dtype=np.uint8))
+    for i in range(0, len(dense) - 5, 7):
+        dense[i] = 0xE8 + int(rng.integers(0, 2))
+        dense[i + 4] = int(rng.choice([0, 255, 1, 254]))
+    cases.append(bytes(dense))
+    for data in cases:
+        want = oracle.run_pcomp(pcomp, data, 0, 0, cap=len(data) + 64)           # whole segment: every byte, then the end-of-segment run
+        out = (ctypes.c_uint8 * (len(data) + 8))()
+        B, Cc = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        k = lib.e8_run(data, len(data), out, ctypes.byref(B), ctypes.byref(Cc))
+        got = bytes(out[:k])
+        # the program's end-of-segment run (`a> 255` branch) from (B, C): C > 4 -> 4 bytes pending, else C bytes after dropping 5 - C
+        b, c = B.value, Cc.value
+        if c > 4:
+            c = 4
+        else:                                                                     # a! a+= 5 a<<= 3 d=a a=b a>>=d b=a
+            b >>= ((((c ^ 0xFFFFFFFF) + 5) & 0xFFFFFFFF) << 3) & 31
+        tail = bytes((b >> (8 * i)) & 255 for i in range(c))
+        assert got + tail == want, (len(data), got[-8:], tail, want[-12:])
